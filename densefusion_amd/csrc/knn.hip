@@ -1,0 +1,149 @@
+// Fused brute-force nearest neighbour for gfx950.
+//
+// Replaces the reference's two-kernel algorithm (lib/knn/src/knn_cuda_kernel.cu:31-95 all-pairs
+// distance matrix in HBM, :107-170 per-column insertion sort) with one pass that never materialises
+// the R x Q matrix: every lane owns QPL query points in registers, the reference points are
+// wave-uniform (read through the scalar cache / broadcast), and the running arg-min lives in VGPRs.
+//
+// Bit-exactness contract (the oracle is oracle/knn_ref.c): the squared distance is accumulated in
+// coordinate order as ssd = fma(t, t, ssd) starting from 0 -- what nvcc's default contraction makes of
+// `ssd += tmp*tmp` (.cu:83-84) -- and a candidate replaces the best only on strict '<', so the lowest
+// reference index wins ties (.cu:128,152).  Indices are written 1-based as int64 (.cu:122,141,165).
+#include "common.h"
+
+namespace {
+
+constexpr int KNN_BLOCK = 256;
+
+// dim == 3, k == 1.  grid = (ceil(Q / (KNN_BLOCK*QPL)), batch)
+template <int QPL>
+__global__ __launch_bounds__(KNN_BLOCK) void knn1_dim3_kernel(const float *__restrict__ ref, int R,
+                                                              const float *__restrict__ query, int Q,
+                                                              int64_t *__restrict__ ind) {
+  extern __shared__ __attribute__((aligned(16))) float s_ref[];   // [R][4] = x,y,z,pad
+  const int b = blockIdx.y;
+  ref += (size_t)b * 3 * R;
+  query += (size_t)b * 3 * Q;
+  ind += (size_t)b * Q;
+
+  for (int r = threadIdx.x; r < R; r += KNN_BLOCK) {
+    float4 p = make_float4(ref[r], ref[R + r], ref[2 * R + r], 0.f);
+    reinterpret_cast<float4 *>(s_ref)[r] = p;
+  }
+  __syncthreads();
+
+  const int q0 = blockIdx.x * (KNN_BLOCK * QPL) + threadIdx.x;
+  float qx[QPL], qy[QPL], qz[QPL], best[QPL];
+  int bi[QPL];
+#pragma unroll
+  for (int j = 0; j < QPL; ++j) {
+    int q = q0 + j * KNN_BLOCK;
+    int qc = q < Q ? q : Q - 1;          // clamp: out-of-range lanes compute on a valid point, never store
+    qx[j] = query[qc];
+    qy[j] = query[Q + qc];
+    qz[j] = query[2 * Q + qc];
+    best[j] = __builtin_inff();
+    bi[j] = 0;
+  }
+
+  // NaN distances never satisfy '<' -- same as the reference's comparison
+#pragma unroll 4
+  for (int r = 0; r < R; ++r) {
+    const float4 p = reinterpret_cast<const float4 *>(s_ref)[r];   // wave-uniform address: LDS broadcast
+#pragma unroll
+    for (int j = 0; j < QPL; ++j) {
+      float tx = p.x - qx[j];
+      float ty = p.y - qy[j];
+      float tz = p.z - qz[j];
+      float d = tx * tx;                 // == fma(tx, tx, 0)
+      d = __builtin_fmaf(ty, ty, d);
+      d = __builtin_fmaf(tz, tz, d);
+      bool lt = d < best[j];
+      best[j] = lt ? d : best[j];
+      bi[j] = lt ? r : bi[j];
+    }
+  }
+  // the reference seeds the column with row 0 unconditionally (.cu:120-122); with best = +inf the first
+  // finite distance wins, and an all-NaN column keeps index 0 -> 1-based 1, the same answer
+#pragma unroll
+  for (int j = 0; j < QPL; ++j) {
+    int q = q0 + j * KNN_BLOCK;
+    if (q < Q) ind[q] = (int64_t)bi[j] + 1;
+  }
+}
+
+// Generic dim / k: one lane per query, sorted top-k kept in registers/scratch (stable: ties keep the
+// lower index first, which is what the reference's insertion with strict comparisons produces).
+template <int KMAX>
+__global__ __launch_bounds__(KNN_BLOCK) void knn_generic_kernel(const float *__restrict__ ref, int R,
+                                                                const float *__restrict__ query, int Q, int dim,
+                                                                int k, int64_t *__restrict__ ind) {
+  const int b = blockIdx.y;
+  ref += (size_t)b * dim * R;
+  query += (size_t)b * dim * Q;
+  ind += (size_t)b * k * Q;
+  const int q = blockIdx.x * KNN_BLOCK + threadIdx.x;
+  if (q >= Q) return;
+  float bd[KMAX];
+  int bidx[KMAX];
+  int filled = 0;
+  for (int r = 0; r < R; ++r) {
+    float ssd = 0.f;
+    for (int d = 0; d < dim; ++d) {
+      float t = ref[(size_t)d * R + r] - query[(size_t)d * Q + q];
+      ssd = __builtin_fmaf(t, t, ssd);
+    }
+    if (filled < k) {
+      // part 1 of cuInsertionSort: place among the first `filled` entries
+      int i = filled;
+      if (filled > 0 && ssd < bd[filled - 1]) {
+        i = filled - 1;
+        for (int a = 0; a < filled - 1; ++a)
+          if (bd[a] > ssd) { i = a; break; }
+      }
+      for (int j = filled; j > i; --j) { bd[j] = bd[j - 1]; bidx[j] = bidx[j - 1]; }
+      bd[i] = ssd;
+      bidx[i] = r;
+      ++filled;
+    } else if (ssd < bd[k - 1]) {
+      int i = k - 1;
+      for (int a = 0; a < k - 1; ++a)
+        if (bd[a] > ssd) { i = a; break; }
+      for (int j = k - 1; j > i; --j) { bd[j] = bd[j - 1]; bidx[j] = bidx[j - 1]; }
+      bd[i] = ssd;
+      bidx[i] = r;
+    }
+  }
+  for (int j = 0; j < k; ++j) ind[(size_t)j * Q + q] = (int64_t)bidx[j] + 1;
+}
+
+int launch_knn(const float *ref, const float *query, int64_t *idx, int batch, int dim, int R, int Q, int k,
+               hipStream_t st) {
+  if (batch < 0 || dim <= 0 || R <= 0 || Q < 0) return df::set_error(DF_ERR_ARG, "knn: bad sizes");
+  if (k <= 0 || k > R || k > DF_KNN_MAX_K)
+    return df::set_error(DF_ERR_ARG, "knn: k=%d must be in [1, min(ref_nb=%d, %d)]", k, R, DF_KNN_MAX_K);
+  if (batch == 0 || Q == 0) return DF_OK;      // empty query set: nothing to write
+  if (!ref || !query || !idx) return df::set_error(DF_ERR_ARG, "knn: null pointer");
+  if (batch > 65535) return df::set_error(DF_ERR_ARG, "knn: batch > 65535");
+  if (dim == 3 && k == 1 && (size_t)R * 16 <= 64 * 1024) {
+    constexpr int QPL = 2;
+    dim3 grid(df::cdiv(Q, KNN_BLOCK * QPL), batch);
+    hipLaunchKernelGGL(knn1_dim3_kernel<QPL>, grid, dim3(KNN_BLOCK), (size_t)R * 16, st, ref, R, query, Q, idx);
+  } else {
+    dim3 grid(df::cdiv(Q, KNN_BLOCK), batch);
+    hipLaunchKernelGGL(knn_generic_kernel<DF_KNN_MAX_K>, grid, dim3(KNN_BLOCK), 0, st, ref, R, query, Q, dim, k, idx);
+  }
+  return df::check_launch("knn");
+}
+
+}  // namespace
+
+extern "C" int df_knn_device(const float *ref_dev, int ref_nb, const float *query_dev, int query_nb, int dim, int k,
+                             int64_t *ind_dev, df_stream_t stream) {
+  return launch_knn(ref_dev, query_dev, ind_dev, 1, dim, ref_nb, query_nb, k, df::to_stream(stream));
+}
+
+extern "C" int df_knn(const float *ref, const float *query, int64_t *idx, int batch, int dim, int ref_nb,
+                      int query_nb, int k, df_stream_t stream) {
+  return launch_knn(ref, query, idx, batch, dim, ref_nb, query_nb, k, df::to_stream(stream));
+}
