@@ -12,7 +12,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdfusion_hip.so")
 _lib = None
 
-_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+_vp, _i, _i64, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of df_conv_desc (include/dfusion.h)."""
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("in_", "wgt", "bias", "res", "prelu", "out")] +
+                [(n, ctypes.c_int32) for n in ("B", "H", "W", "Cin", "in_ld", "in_coff", "OH", "OW", "Cout", "out_ld",
+                                               "out_coff", "res_ld", "res_coff", "KH", "KW", "stride", "pad", "dil",
+                                               "act")])
+
 
 # symbol -> (restype, argtypes); must list every function include/dfusion.h declares
 SIGNATURES = {
@@ -20,6 +28,21 @@ SIGNATURES = {
     "df_version": (_i, []),
     "df_knn_device": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "df_knn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "df_posenet_create": (_vp, [_i, _i]),
+    "df_refiner_create": (_vp, [_i, _i]),
+    "df_net_destroy": (None, [_vp]),
+    "df_net_num_params": (_i, [_vp]),
+    "df_net_param_info": (_i, [_vp, _i, ctypes.c_char_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i)]),
+    "df_net_load_param": (_i, [_vp, ctypes.c_char_p, _vp, _i64]),
+    "df_posenet_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "df_posenet_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "df_refiner_workspace_bytes": (_sz, [_vp, _i]),
+    "df_refiner_forward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "df_estimate_workspace_bytes": (_sz, [_vp, _vp, _i, _i, _i]),
+    "df_estimate_poses": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "df_conv2d_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp]),
+    "df_net_profile": (_i, [_vp, _i]),
+    "df_net_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i)]),
 }
 
 

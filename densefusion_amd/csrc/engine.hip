@@ -1,0 +1,708 @@
+// Host-side engine of libdfusion_hip.so: parameter store in kernel-friendly layouts, workspace
+// planning, and the launch sequences of PoseNet.forward / PoseRefineNet.forward / the fused
+// "estimate poses" pipeline (PoseNet -> per-pixel selection -> refine loop), all on one stream with
+// no host synchronisation, no allocation and no host<->device copies inside a forward call.
+//
+// Reference behaviour mirrored: lib/network.py:95-132 (PoseNet.forward), :187-206
+// (PoseRefineNet.forward), lib/pspnet.py:64-77, lib/extractors.py:114-124, tools/eval_ycb.py:192-229.
+// Batch extension: the reference evaluates one object per call (b = 0 hard-coded, network.py:123);
+// every entry point here takes B same-sized objects and evaluates them independently.
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "igemm.h"
+#include "layers.h"
+#include "pose.h"
+
+namespace df {
+
+// ------------------------------------------------------------------------------------------------
+// parameter store
+// ------------------------------------------------------------------------------------------------
+struct ParamInfo {
+  std::string key;
+  int64_t shape[4];
+  int ndim;
+  int64_t numel() const { int64_t n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i]; return n; }
+};
+
+struct Net {
+  int kind = 0;   // 0 = PoseNet, 1 = PoseRefineNet
+  int num_points = 0, num_obj = 0;
+  std::vector<ParamInfo> spec;
+  std::map<std::string, int> index;
+  std::vector<char> loaded;
+  std::map<std::string, float *> buf;   // packed device buffers by internal name
+  int device = 0;
+  // profiling of GEMM launches (bench.py roofline): event pairs around every launch_conv
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<double> ev_flops;
+  size_t ev_used = 0;
+};
+
+static void add(Net &n, const std::string &key, std::initializer_list<int64_t> shp) {
+  ParamInfo p;
+  p.key = key;
+  p.ndim = (int)shp.size();
+  int i = 0;
+  for (auto v : shp) p.shape[i++] = v;
+  for (; i < 4; ++i) p.shape[i] = 1;
+  n.index[key] = (int)n.spec.size();
+  n.spec.push_back(p);
+}
+
+static const char *CNN = "cnn.model.module.";
+
+static void build_posenet_spec(Net &n) {
+  const std::string c = CNN;
+  add(n, c + "feats.conv1.weight", {64, 3, 7, 7});
+  int inpl = 64;
+  const int planes_of[4] = {64, 128, 256, 512};
+  for (int li = 1; li <= 4; ++li) {
+    const int planes = planes_of[li - 1];
+    for (int blk = 0; blk < 2; ++blk) {
+      const int cin = blk == 0 ? inpl : planes;
+      const std::string base = c + "feats.layer" + std::to_string(li) + "." + std::to_string(blk) + ".";
+      add(n, base + "conv1.weight", {planes, cin, 3, 3});
+      add(n, base + "conv2.weight", {planes, planes, 3, 3});
+      if (blk == 0 && cin != planes) add(n, base + "downsample.0.weight", {planes, cin, 1, 1});
+    }
+    inpl = planes;
+  }
+  for (int s = 0; s < 4; ++s) add(n, c + "psp.stages." + std::to_string(s) + ".1.weight", {512, 512, 1, 1});
+  add(n, c + "psp.bottleneck.weight", {1024, 2560, 1, 1});
+  add(n, c + "psp.bottleneck.bias", {1024});
+  const char *ups[3] = {"up_1", "up_2", "up_3"};
+  const int up_in[3] = {1024, 256, 64}, up_out[3] = {256, 64, 64};
+  for (int u = 0; u < 3; ++u) {
+    add(n, c + ups[u] + ".conv.1.weight", {up_out[u], up_in[u], 3, 3});
+    add(n, c + ups[u] + ".conv.1.bias", {up_out[u]});
+    add(n, c + ups[u] + ".conv.2.weight", {1});
+  }
+  add(n, c + "final.0.weight", {32, 64, 1, 1});
+  add(n, c + "final.0.bias", {32});
+  add(n, c + "classifier.0.weight", {256, 256});   // dead weights (lib/pspnet.py:58-62): accepted, unused
+  add(n, c + "classifier.0.bias", {256});
+  add(n, c + "classifier.2.weight", {21, 256});
+  add(n, c + "classifier.2.bias", {21});
+  const char *fn[6] = {"conv1", "conv2", "e_conv1", "e_conv2", "conv5", "conv6"};
+  const int fi[6] = {3, 64, 32, 64, 256, 512}, fo[6] = {64, 128, 64, 128, 512, 1024};
+  for (int i = 0; i < 6; ++i) {
+    add(n, std::string("feat.") + fn[i] + ".weight", {fo[i], fi[i], 1});
+    add(n, std::string("feat.") + fn[i] + ".bias", {fo[i]});
+  }
+  const int hin[3] = {1408, 640, 256}, hout[3] = {640, 256, 128};
+  const char *hs[3] = {"r", "t", "c"};
+  for (int l = 0; l < 3; ++l)
+    for (int h = 0; h < 3; ++h) {
+      const std::string nm = "conv" + std::to_string(l + 1) + "_" + hs[h];
+      add(n, nm + ".weight", {hout[l], hin[l], 1});
+      add(n, nm + ".bias", {hout[l]});
+    }
+  const int per[3] = {4, 3, 1};
+  for (int h = 0; h < 3; ++h) {
+    const std::string nm = std::string("conv4_") + hs[h];
+    add(n, nm + ".weight", {(int64_t)n.num_obj * per[h], 128, 1});
+    add(n, nm + ".bias", {(int64_t)n.num_obj * per[h]});
+  }
+}
+
+static void build_refiner_spec(Net &n) {
+  const char *fn[6] = {"conv1", "conv2", "e_conv1", "e_conv2", "conv5", "conv6"};
+  const int fi[6] = {3, 64, 32, 64, 384, 512}, fo[6] = {64, 128, 64, 128, 512, 1024};
+  for (int i = 0; i < 6; ++i) {
+    add(n, std::string("feat.") + fn[i] + ".weight", {fo[i], fi[i], 1});
+    add(n, std::string("feat.") + fn[i] + ".bias", {fo[i]});
+  }
+  const int li[2] = {1024, 512}, lo[2] = {512, 128};
+  const char *hs[2] = {"r", "t"};
+  for (int l = 0; l < 2; ++l)
+    for (int h = 0; h < 2; ++h) {
+      const std::string nm = "conv" + std::to_string(l + 1) + "_" + hs[h];
+      add(n, nm + ".weight", {lo[l], li[l]});
+      add(n, nm + ".bias", {lo[l]});
+    }
+  const int per[2] = {4, 3};
+  for (int h = 0; h < 2; ++h) {
+    const std::string nm = std::string("conv3_") + hs[h];
+    add(n, nm + ".weight", {(int64_t)n.num_obj * per[h], 128});
+    add(n, nm + ".bias", {(int64_t)n.num_obj * per[h]});
+  }
+}
+
+static float *dev_alloc(Net &n, const std::string &name, size_t floats) {
+  auto it = n.buf.find(name);
+  if (it != n.buf.end()) return it->second;
+  float *p = nullptr;
+  if (hipMalloc(&p, floats * sizeof(float)) != hipSuccess) return nullptr;
+  hipMemset(p, 0, floats * sizeof(float));
+  n.buf[name] = p;
+  return p;
+}
+
+// OIHW -> O (H W) Ipad
+__global__ void pack_oihw_kernel(const float *__restrict__ src, float *__restrict__ dst, int O, int I, int HW, int Ipad) {
+  const long total = (long)O * HW * Ipad;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % Ipad);
+    const long r = i / Ipad;
+    const int t = (int)(r % HW);
+    const long o = r / HW;
+    dst[i] = c < I ? src[(o * I + c) * HW + t] : 0.f;
+  }
+}
+
+static bool ends_with(const std::string &s, const char *suf) {
+  const size_t l = strlen(suf);
+  return s.size() >= l && s.compare(s.size() - l, l, suf) == 0;
+}
+
+// copies `src` (device, reference layout) into the packed store
+static int load_param(Net &n, const std::string &key, const float *src, int64_t numel) {
+  auto it = n.index.find(key);
+  if (it == n.index.end()) return set_error(DF_ERR_ARG, "load_param: unexpected key '%s'", key.c_str());
+  const ParamInfo &pi = n.spec[it->second];
+  if (numel != pi.numel())
+    return set_error(DF_ERR_ARG, "load_param: size mismatch for %s: got %lld elements, expected %lld", key.c_str(),
+                     (long long)numel, (long long)pi.numel());
+  if (!src) return set_error(DF_ERR_ARG, "load_param: null pointer for %s", key.c_str());
+  hipSetDevice(n.device);
+  auto copy = [&](float *dst, const float *s, size_t cnt) { return hipMemcpy(dst, s, cnt * sizeof(float), hipMemcpyDefault); };
+  auto copy2d = [&](float *dst, size_t dld, const float *s, size_t sld, size_t width, size_t rows) {
+    return hipMemcpy2D(dst, dld * sizeof(float), s, sld * sizeof(float), width * sizeof(float), rows, hipMemcpyDefault);
+  };
+  hipError_t e = hipSuccess;
+  if (pi.ndim == 4 && !ends_with(key, "classifier.0.weight")) {
+    const int O = (int)pi.shape[0], I = (int)pi.shape[1], HW = (int)(pi.shape[2] * pi.shape[3]);
+    const int Ipad = (I + 3) / 4 * 4;
+    float *dst = dev_alloc(n, key, (size_t)O * HW * Ipad);
+    if (!dst) return set_error(DF_ERR_LAUNCH, "load_param: hipMalloc failed");
+    if (HW == 1 && Ipad == I) e = copy(dst, src, (size_t)numel);
+    else {
+      // src may be a host pointer: stage through a device temp
+      float *tmp = nullptr;
+      if (hipMalloc(&tmp, numel * sizeof(float)) != hipSuccess) return set_error(DF_ERR_LAUNCH, "hipMalloc failed");
+      e = copy(tmp, src, (size_t)numel);
+      hipLaunchKernelGGL(pack_oihw_kernel, dim3(256), dim3(256), 0, 0, tmp, dst, O, I, HW, Ipad);
+      hipDeviceSynchronize();
+      hipFree(tmp);
+    }
+  } else if (n.kind == 0 && key.rfind("conv1_", 0) == 0) {
+    // head layer 1 of tower h: split [640][1408] into the per-point part (first 384 input channels =
+    // pointfeat_1|pointfeat_2) and the broadcast global-feature part (last 1024), towers stacked r,t,c
+    const int h = key[6] == 'r' ? 0 : key[6] == 't' ? 1 : 2;
+    if (ends_with(key, ".weight")) {
+      float *wpt = dev_alloc(n, "head1.wpt", (size_t)1920 * 384), *wg = dev_alloc(n, "head1.wg", (size_t)1920 * 1024);
+      if (!wpt || !wg) return set_error(DF_ERR_LAUNCH, "hipMalloc failed");
+      e = copy2d(wpt + (size_t)h * 640 * 384, 384, src, 1408, 384, 640);
+      if (e == hipSuccess) e = copy2d(wg + (size_t)h * 640 * 1024, 1024, src + 384, 1408, 1024, 640);
+    } else {
+      float *b = dev_alloc(n, "head1.bias", 1920);
+      e = copy(b + h * 640, src, 640);
+    }
+  } else if (n.kind == 0 && (key.rfind("conv2_", 0) == 0 || key.rfind("conv3_", 0) == 0)) {
+    const int l = key[4] - '0';
+    const int h = key[6] == 'r' ? 0 : key[6] == 't' ? 1 : 2;
+    const int co = l == 2 ? 256 : 128, ci = l == 2 ? 640 : 256;
+    const std::string nm = std::string("head") + std::to_string(l);
+    if (ends_with(key, ".weight")) e = copy(dev_alloc(n, nm + ".w", (size_t)3 * co * ci) + (size_t)h * co * ci, src, (size_t)co * ci);
+    else e = copy(dev_alloc(n, nm + ".bias", 3 * co) + h * co, src, co);
+  } else if (n.kind == 1 && (key.rfind("conv1_", 0) == 0 || key.rfind("conv2_", 0) == 0)) {
+    const int l = key[4] - '0';
+    const int h = key[6] == 'r' ? 0 : 1;
+    const int co = l == 1 ? 512 : 128, ci = l == 1 ? 1024 : 512;
+    const std::string nm = std::string("fc") + std::to_string(l);
+    if (ends_with(key, ".weight")) e = copy(dev_alloc(n, nm + ".w", (size_t)2 * co * ci) + (size_t)h * co * ci, src, (size_t)co * ci);
+    else e = copy(dev_alloc(n, nm + ".bias", 2 * co) + h * co, src, co);
+  } else {
+    float *dst = dev_alloc(n, key, (size_t)numel);
+    if (!dst) return set_error(DF_ERR_LAUNCH, "load_param: hipMalloc failed");
+    e = copy(dst, src, (size_t)numel);
+  }
+  if (e != hipSuccess) return set_error(DF_ERR_LAUNCH, "load_param(%s): %s", key.c_str(), hipGetErrorString(e));
+  n.loaded[it->second] = 1;
+  return DF_OK;
+}
+
+static int check_ready(const Net &n) {
+  for (size_t i = 0; i < n.spec.size(); ++i)
+    if (!n.loaded[i]) return set_error(DF_ERR_STATE, "parameter '%s' was never loaded", n.spec[i].key.c_str());
+  return DF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward plumbing
+// ------------------------------------------------------------------------------------------------
+struct Ctx {
+  Net *net;
+  hipStream_t st;
+  bool dry;          // dry run: only measure the workspace
+  char *base;
+  size_t off = 0, cap = 0;
+  int err = DF_OK;
+
+  float *f(size_t floats) { return reinterpret_cast<float *>(bytes(floats * sizeof(float))); }
+  void *bytes(size_t b) {
+    b = (b + 255) & ~size_t(255);
+    void *p = dry ? nullptr : base + off;
+    off += b;
+    if (!dry && off > cap && err == DF_OK) err = set_error(DF_ERR_WORKSPACE, "workspace too small: need > %zu bytes, have %zu", off, cap);
+    return p;
+  }
+  bool live() const { return !dry && err == DF_OK; }
+  const float *w(const std::string &name) {
+    auto it = net->buf.find(name);
+    if (it == net->buf.end()) {
+      if (err == DF_OK) err = set_error(DF_ERR_STATE, "missing packed parameter '%s'", name.c_str());
+      return nullptr;
+    }
+    return it->second;
+  }
+  void conv(const ConvParams &p) {
+    if (!live()) return;
+    Net &n = *net;
+    if (n.profiling) {
+      if (n.ev_used + 2 > n.ev.size()) {
+        const size_t old = n.ev.size();
+        n.ev.resize(old + 256);
+        for (size_t i = old; i < n.ev.size(); ++i) hipEventCreate(&n.ev[i]);
+      }
+      hipEventRecord(n.ev[n.ev_used], st);
+    }
+    const int rc = launch_conv(p, st);
+    if (n.profiling) {
+      hipEventRecord(n.ev[n.ev_used + 1], st);
+      n.ev_flops.push_back(conv_flops(p));
+      n.ev_used += 2;
+    }
+    if (rc != DF_OK) err = rc;
+  }
+};
+
+static ConvParams point_gemm(const float *in, int in_ld, int in_coff, int cin, const float *w, const float *bias,
+                             float *out, int out_ld, int out_coff, int cout, int rows, int act) {
+  ConvParams p;
+  p.in = in; p.wgt = w; p.bias = bias; p.out = out;
+  p.B = rows; p.H = p.W = p.OH = p.OW = 1;
+  p.Cin = cin; p.in_ld = in_ld; p.in_coff = in_coff;
+  p.Cout = cout; p.out_ld = out_ld; p.out_coff = out_coff;
+  p.act = act;
+  return p;
+}
+
+static ConvParams conv2d(const float *in, int B, int H, int W, int cin, int in_ld, const float *w, const float *bias,
+                         float *out, int OH, int OW, int cout, int out_ld, int out_coff, int k, int stride, int pad,
+                         int dil, int act) {
+  ConvParams p;
+  p.in = in; p.wgt = w; p.bias = bias; p.out = out;
+  p.B = B; p.H = H; p.W = W; p.OH = OH; p.OW = OW;
+  p.Cin = cin; p.in_ld = in_ld; p.Cout = cout; p.out_ld = out_ld; p.out_coff = out_coff;
+  p.KH = p.KW = k; p.stride = stride; p.pad = pad; p.dil = dil; p.act = act;
+  return p;
+}
+
+static inline int conv_out(int in, int k, int stride, int pad, int dil) { return (in + 2 * pad - dil * (k - 1) - 1) / stride + 1; }
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct PoseNetOut {
+  float *out_r, *out_t, *out_c, *emb;   // caller buffers
+  float *emb_pm = nullptr;              // [B][Npad][32] inside the workspace
+};
+
+// PSPNet colour branch + gather: lib/pspnet.py:64-77 on top of lib/extractors.py:114-124
+static float *cnn_forward(Ctx &c, int B, int H, int W, const float *img, int &outH, int &outW) {
+  const std::string P = CNN;
+  float *img4 = c.f((size_t)B * H * W * 4);
+  if (c.live()) launch_nchw3_to_nhwc4(img, img4, B, H, W, c.st);
+  const int H1 = conv_out(H, 7, 2, 3, 1), W1 = conv_out(W, 7, 2, 3, 1);
+  float *stem = c.f((size_t)B * H1 * W1 * 64);
+  c.conv(conv2d(img4, B, H, W, 4, 4, c.w(P + "feats.conv1.weight"), nullptr, stem, H1, W1, 64, 64, 0, 7, 2, 3, 1, ACT_RELU));
+  const int H2 = conv_out(H1, 3, 2, 1, 1), W2 = conv_out(W1, 3, 2, 1, 1);
+  float *x = c.f((size_t)B * H2 * W2 * 64);
+  if (c.live()) launch_maxpool3s2(stem, x, B, H1, W1, 64, H2, W2, c.st);
+
+  int h = H2, w = W2, cin = 64, x_ld = 64;
+  const int planes_of[4] = {64, 128, 256, 512}, stride_of[4] = {1, 2, 1, 1}, dil_of[4] = {1, 1, 2, 4};
+  float *concat = nullptr;
+  for (int li = 1; li <= 4; ++li) {
+    const int planes = planes_of[li - 1], s = stride_of[li - 1], d = dil_of[li - 1];
+    const std::string base = P + "feats.layer" + std::to_string(li) + ".";
+    // block 0: built without dilation (lib/extractors.py:107); carries the stride and the 1x1 downsample
+    const int oh = conv_out(h, 3, s, 1, 1), ow = conv_out(w, 3, s, 1, 1);
+    float *t = c.f((size_t)B * oh * ow * planes);
+    c.conv(conv2d(x, B, h, w, cin, x_ld, c.w(base + "0.conv1.weight"), nullptr, t, oh, ow, planes, planes, 0, 3, s, 1, 1, ACT_RELU));
+    const float *res = x;
+    int res_ld = x_ld;
+    if (cin != planes || s != 1) {
+      float *ds = c.f((size_t)B * oh * ow * planes);
+      c.conv(conv2d(x, B, h, w, cin, x_ld, c.w(base + "0.downsample.0.weight"), nullptr, ds, oh, ow, planes, planes, 0, 1, s, 0, 1, ACT_NONE));
+      res = ds;
+      res_ld = planes;
+    }
+    float *o0 = c.f((size_t)B * oh * ow * planes);
+    {
+      ConvParams p = conv2d(t, B, oh, ow, planes, planes, c.w(base + "0.conv2.weight"), nullptr, o0, oh, ow, planes, planes, 0, 3, 1, 1, 1, ACT_RELU);
+      p.res = res; p.res_ld = res_ld;
+      c.conv(p);
+    }
+    // block 1: dilated (lib/extractors.py:110)
+    float *t1 = c.f((size_t)B * oh * ow * planes);
+    c.conv(conv2d(o0, B, oh, ow, planes, planes, c.w(base + "1.conv1.weight"), nullptr, t1, oh, ow, planes, planes, 0, 3, 1, d, d, ACT_RELU));
+    float *o1;
+    int o1_ld = planes, o1_coff = 0;
+    if (li == 4) {   // feats go straight into the last 512 channels of the PSP concat buffer (pspnet.py:22)
+      concat = c.f((size_t)B * oh * ow * 2560);
+      o1 = concat; o1_ld = 2560; o1_coff = 2048;
+    } else {
+      o1 = c.f((size_t)B * oh * ow * planes);
+    }
+    {
+      ConvParams p = conv2d(t1, B, oh, ow, planes, planes, c.w(base + "1.conv2.weight"), nullptr, o1, oh, ow, planes, o1_ld, o1_coff, 3, 1, d, d, ACT_RELU);
+      p.res = o0; p.res_ld = planes;
+      c.conv(p);
+    }
+    x = o1; x_ld = o1_ld; h = oh; w = ow; cin = planes;
+  }
+  // PSP module (lib/pspnet.py:20-24)
+  float *pooled = c.f((size_t)50 * B * 512), *stg = c.f((size_t)50 * B * 512);
+  if (c.live()) launch_psp_pool(concat, 2560, 2048, pooled, B, h, w, 512, c.st);
+  const int soff[4] = {0, 1, 5, 14}, ssz[4] = {1, 4, 9, 36};
+  for (int s = 0; s < 4; ++s)
+    c.conv(point_gemm(pooled ? pooled + (size_t)soff[s] * B * 512 : nullptr, 512, 0, 512, c.w(P + "psp.stages." + std::to_string(s) + ".1.weight"),
+                      nullptr, stg ? stg + (size_t)soff[s] * B * 512 : nullptr, 512, 0, 512, B * ssz[s], ACT_NONE));
+  if (c.live()) launch_psp_upsample_concat(stg, concat, 2560, B, h, w, 512, c.st);
+  float *psp = c.f((size_t)B * h * w * 1024);
+  c.conv(point_gemm(concat, 2560, 0, 2560, c.w(P + "psp.bottleneck.weight"), c.w(P + "psp.bottleneck.bias"), psp, 1024, 0, 1024, B * h * w, ACT_RELU));
+  // three x2 upsample + 3x3 conv + PReLU stages (lib/pspnet.py:27-37,69-75; dropout = identity in eval)
+  float *cur = psp;
+  const char *ups[3] = {"up_1", "up_2", "up_3"};
+  const int up_in[3] = {1024, 256, 64}, up_out[3] = {256, 64, 64};
+  for (int u = 0; u < 3; ++u) {
+    float *big = c.f((size_t)B * 4 * h * w * up_in[u]);
+    if (c.live()) launch_upsample2x_ac(cur, big, B, h, w, up_in[u], c.st);
+    h *= 2; w *= 2;
+    float *o = c.f((size_t)B * h * w * up_out[u]);
+    ConvParams p = conv2d(big, B, h, w, up_in[u], up_in[u], c.w(P + ups[u] + ".conv.1.weight"), c.w(P + ups[u] + ".conv.1.bias"), o, h, w,
+                          up_out[u], up_out[u], 0, 3, 1, 1, 1, ACT_PRELU);
+    p.prelu = c.w(P + ups[u] + ".conv.2.weight");
+    c.conv(p);
+    cur = o;
+  }
+  outH = h; outW = w;
+  return cur;   // [B][h][w][64], the input of final.0
+}
+
+// PoseNetFeat + heads (lib/network.py:53-68,107-131) on point-major rows padded to Npad per object
+static void posenet_points(Ctx &c, int B, int N, int Npad, const float *cloud, const float *emb_pm, const int64_t *obj,
+                           float *out_r, float *out_t, float *out_c) {
+  Net &n = *c.net;
+  const int rows = B * Npad;
+  float *pf = c.f((size_t)rows * 384);          // [x1 64 | e1 64 | x2 128 | e2 128] = pointfeat_1 | pointfeat_2
+  if (c.live()) launch_cloud_conv1(cloud, nullptr, c.w("feat.conv1.weight"), c.w("feat.conv1.bias"), pf, 384, B, N, Npad, c.st);
+  c.conv(point_gemm(emb_pm, 32, 0, 32, c.w("feat.e_conv1.weight"), c.w("feat.e_conv1.bias"), pf, 384, 64, 64, rows, ACT_RELU));
+  c.conv(point_gemm(pf, 384, 0, 64, c.w("feat.conv2.weight"), c.w("feat.conv2.bias"), pf, 384, 128, 128, rows, ACT_RELU));
+  c.conv(point_gemm(pf, 384, 64, 64, c.w("feat.e_conv2.weight"), c.w("feat.e_conv2.bias"), pf, 384, 256, 128, rows, ACT_RELU));
+  float *x5 = c.f((size_t)rows * 512);
+  c.conv(point_gemm(pf, 384, 128, 256, c.w("feat.conv5.weight"), c.w("feat.conv5.bias"), x5, 512, 0, 512, rows, ACT_RELU));
+  // conv6 + ReLU + AvgPool1d(N): the 1024-wide activation is consumed only by the mean, so it never
+  // leaves the GEMM's registers -- per-wave column sums, then a tiny deterministic reduction
+  ConvParams p6 = point_gemm(x5, 512, 0, 512, c.w("feat.conv6.weight"), c.w("feat.conv6.bias"), nullptr, 1024, 0, 1024, rows, ACT_RELU);
+  p6.rows_per_group = Npad; p6.rows_valid = N;
+  const int prow = conv_colsum_rows(p6);
+  float *partial = c.f((size_t)prow * 1024);
+  p6.colsum = partial;
+  c.conv(p6);
+  float *apx = c.f((size_t)B * 1024);
+  if (c.live()) launch_colsum_finish(partial, prow / B, apx, B, 1024, N, c.st);
+  // head layer 1: W[:, :384] . pointfeat + (W[:, 384:] . ap_x + b) -- the 1024 broadcast channels of the
+  // 1408-wide input are identical for every point of an object, so they collapse into a per-object bias
+  float *gbias = c.f((size_t)B * 1920);
+  if (c.live()) launch_linear_rows(apx, 1024, 0, c.w("head1.wg"), c.w("head1.bias"), gbias, 1920, B, 1024, 1920, 1, 0, c.st);
+  float *h1 = c.f((size_t)rows * 1920);
+  {
+    ConvParams p = point_gemm(pf, 384, 0, 384, c.w("head1.wpt"), gbias, h1, 1920, 0, 1920, rows, ACT_RELU);
+    p.rows_per_group = Npad; p.rows_valid = N; p.bias_group_ld = 1920;
+    c.conv(p);
+  }
+  float *h2 = c.f((size_t)rows * 768), *h3 = c.f((size_t)rows * 384);
+  {
+    ConvParams p = point_gemm(h1, 1920, 0, 640, c.w("head2.w"), c.w("head2.bias"), h2, 768, 0, 256, rows, ACT_RELU);
+    p.zcount = 3; p.z_in_coff = 640; p.z_wgt = 256 * 640; p.z_bias = 256; p.z_out_coff = 256;
+    c.conv(p);
+  }
+  {
+    ConvParams p = point_gemm(h2, 768, 0, 256, c.w("head3.w"), c.w("head3.bias"), h3, 384, 0, 128, rows, ACT_RELU);
+    p.zcount = 3; p.z_in_coff = 256; p.z_wgt = 128 * 256; p.z_bias = 128; p.z_out_coff = 128;
+    c.conv(p);
+  }
+  if (c.live())
+    launch_head_final(h3, c.w("conv4_r.weight"), c.w("conv4_r.bias"), c.w("conv4_t.weight"), c.w("conv4_t.bias"),
+                      c.w("conv4_c.weight"), c.w("conv4_c.bias"), obj, n.num_obj, out_r, out_t, out_c, B, N, Npad, c.st);
+}
+
+static void posenet_forward(Ctx &c, int B, int H, int W, const float *img, const float *cloud, const int64_t *choose,
+                            const int64_t *obj, PoseNetOut &o) {
+  const int N = c.net->num_points, Npad = round_up(N, 128);
+  int fh = 0, fw = 0;
+  float *feat = cnn_forward(c, B, H, W, img, fh, fw);
+  o.emb_pm = c.f((size_t)B * Npad * 32);
+  if (c.live())
+    launch_gather_final_logsoftmax(feat, choose, c.w(std::string(CNN) + "final.0.weight"), c.w(std::string(CNN) + "final.0.bias"),
+                                   o.emb, o.emb_pm, B, fh * fw, N, Npad, c.st);
+  posenet_points(c, B, N, Npad, cloud, o.emb_pm, obj, o.out_r, o.out_t, o.out_c);
+}
+
+// PoseRefineNetFeat + FC towers (lib/network.py:151-168,187-204).  The emb branch (e_conv1/e_conv2) does
+// not depend on the cloud, so `prepare` runs it once per object and `iterate` re-does only the xyz branch.
+struct RefinerBufs { float *pf, *x5, *partial, *apx, *f1, *f2; int prow; };
+
+static RefinerBufs refiner_alloc(Ctx &c, int B, int N, int Npad) {
+  RefinerBufs r;
+  const int rows = B * Npad;
+  r.pf = c.f((size_t)rows * 384);
+  r.x5 = c.f((size_t)rows * 512);
+  ConvParams p6 = point_gemm(r.x5, 512, 0, 512, nullptr, nullptr, nullptr, 1024, 0, 1024, rows, ACT_RELU);
+  p6.rows_per_group = Npad; p6.rows_valid = N;
+  r.prow = conv_colsum_rows(p6);
+  r.partial = c.f((size_t)r.prow * 1024);
+  r.apx = c.f((size_t)B * 1024);
+  r.f1 = c.f((size_t)B * 1024);
+  r.f2 = c.f((size_t)B * 256);
+  return r;
+}
+
+static void refiner_prepare(Ctx &c, const RefinerBufs &r, int B, int Npad, const float *emb_pm) {
+  const int rows = B * Npad;
+  c.conv(point_gemm(emb_pm, 32, 0, 32, c.w("feat.e_conv1.weight"), c.w("feat.e_conv1.bias"), r.pf, 384, 64, 64, rows, ACT_RELU));
+  c.conv(point_gemm(r.pf, 384, 64, 64, c.w("feat.e_conv2.weight"), c.w("feat.e_conv2.bias"), r.pf, 384, 256, 128, rows, ACT_RELU));
+}
+
+static void refiner_iterate(Ctx &c, const RefinerBufs &r, int B, int N, int Npad, const float *cloud, const float *rt,
+                            const int64_t *obj, float *out_r, float *out_t, double *state, float *rt_next, double *pose_out) {
+  const int rows = B * Npad;
+  if (c.live()) launch_cloud_conv1(cloud, rt, c.w("feat.conv1.weight"), c.w("feat.conv1.bias"), r.pf, 384, B, N, Npad, c.st);
+  c.conv(point_gemm(r.pf, 384, 0, 64, c.w("feat.conv2.weight"), c.w("feat.conv2.bias"), r.pf, 384, 128, 128, rows, ACT_RELU));
+  c.conv(point_gemm(r.pf, 384, 0, 384, c.w("feat.conv5.weight"), c.w("feat.conv5.bias"), r.x5, 512, 0, 512, rows, ACT_RELU));
+  ConvParams p6 = point_gemm(r.x5, 512, 0, 512, c.w("feat.conv6.weight"), c.w("feat.conv6.bias"), nullptr, 1024, 0, 1024, rows, ACT_RELU);
+  p6.rows_per_group = Npad; p6.rows_valid = N; p6.colsum = r.partial;
+  c.conv(p6);
+  if (c.live()) {
+    launch_colsum_finish(r.partial, r.prow / B, r.apx, B, 1024, N, c.st);
+    launch_linear_rows(r.apx, 1024, 0, c.w("fc1.w"), c.w("fc1.bias"), r.f1, 1024, B, 1024, 1024, 1, 1, c.st);
+    launch_linear_rows(r.f1, 1024, 512, c.w("fc2.w"), c.w("fc2.bias"), r.f2, 256, B, 512, 128, 2, 1, c.st);
+    launch_refiner_tail(r.f2, c.w("conv3_r.weight"), c.w("conv3_r.bias"), c.w("conv3_t.weight"), c.w("conv3_t.bias"), obj,
+                        c.net->num_obj, out_r, out_t, state, rt_next, pose_out, B, c.st);
+  }
+}
+
+static Net *as_net(df_net *h) { return reinterpret_cast<Net *>(h); }
+static const Net *as_net(const df_net *h) { return reinterpret_cast<const Net *>(h); }
+
+static int finish(Ctx &c, const char *what) {
+  if (c.err != DF_OK) return c.err;
+  return c.dry ? DF_OK : check_launch(what);
+}
+
+}  // namespace df
+
+using namespace df;
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" df_net *df_posenet_create(int num_points, int num_obj) {
+  if (num_points <= 0 || num_obj <= 0) { set_error(DF_ERR_ARG, "posenet_create: bad sizes"); return nullptr; }
+  Net *n = new Net();
+  n->kind = 0; n->num_points = num_points; n->num_obj = num_obj;
+  hipGetDevice(&n->device);
+  build_posenet_spec(*n);
+  n->loaded.assign(n->spec.size(), 0);
+  return reinterpret_cast<df_net *>(n);
+}
+
+extern "C" df_net *df_refiner_create(int num_points, int num_obj) {
+  if (num_points <= 0 || num_obj <= 0) { set_error(DF_ERR_ARG, "refiner_create: bad sizes"); return nullptr; }
+  Net *n = new Net();
+  n->kind = 1; n->num_points = num_points; n->num_obj = num_obj;
+  hipGetDevice(&n->device);
+  build_refiner_spec(*n);
+  n->loaded.assign(n->spec.size(), 0);
+  return reinterpret_cast<df_net *>(n);
+}
+
+extern "C" void df_net_destroy(df_net *h) {
+  if (!h) return;
+  Net *n = as_net(h);
+  for (auto &kv : n->buf) hipFree(kv.second);
+  for (auto e : n->ev) hipEventDestroy(e);
+  delete n;
+}
+
+extern "C" int df_net_num_params(const df_net *h) { return h ? (int)as_net(h)->spec.size() : 0; }
+
+extern "C" int df_net_param_info(const df_net *h, int i, char *key_out, int key_cap, int64_t *shape4, int *ndim) {
+  if (!h) return set_error(DF_ERR_ARG, "param_info: null handle");
+  const Net *n = as_net(h);
+  if (i < 0 || i >= (int)n->spec.size()) return set_error(DF_ERR_ARG, "param_info: index out of range");
+  const ParamInfo &p = n->spec[i];
+  if (key_out && key_cap > 0) { strncpy(key_out, p.key.c_str(), key_cap - 1); key_out[key_cap - 1] = 0; }
+  if (shape4) for (int d = 0; d < 4; ++d) shape4[d] = p.shape[d];
+  if (ndim) *ndim = p.ndim;
+  return DF_OK;
+}
+
+extern "C" int df_net_load_param(df_net *h, const char *key, const float *ptr, int64_t numel) {
+  if (!h || !key) return set_error(DF_ERR_ARG, "load_param: null handle/key");
+  return load_param(*as_net(h), key, ptr, numel);
+}
+
+extern "C" int df_net_profile(df_net *h, int enable) {
+  if (!h) return set_error(DF_ERR_ARG, "profile: null handle");
+  Net *n = as_net(h);
+  n->profiling = enable != 0;
+  n->ev_used = 0;
+  n->ev_flops.clear();
+  return DF_OK;
+}
+
+// after a stream sync: sum of GEMM launch durations (ms), their algorithmic FLOPs and count since df_net_profile(1)
+extern "C" int df_net_profile_read(df_net *h, double *gemm_ms, double *gemm_flops, int *launches) {
+  if (!h) return set_error(DF_ERR_ARG, "profile_read: null handle");
+  Net *n = as_net(h);
+  double ms = 0, fl = 0;
+  for (size_t i = 0; i + 1 < n->ev_used; i += 2) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, n->ev[i], n->ev[i + 1]) != hipSuccess) return set_error(DF_ERR_LAUNCH, "profile_read: events not complete");
+    ms += t;
+    fl += n->ev_flops[i / 2];
+  }
+  if (gemm_ms) *gemm_ms = ms;
+  if (gemm_flops) *gemm_flops = fl;
+  if (launches) *launches = (int)(n->ev_used / 2);
+  n->ev_used = 0;
+  n->ev_flops.clear();
+  return DF_OK;
+}
+
+static int posenet_args_ok(const Net *n, int B, int H, int W) {
+  if (!n || n->kind != 0) return set_error(DF_ERR_ARG, "not a PoseNet handle");
+  if (B <= 0 || H < 8 || W < 8) return set_error(DF_ERR_ARG, "posenet: need B >= 1 and H, W >= 8 (got %d, %d, %d)", B, H, W);
+  return DF_OK;
+}
+
+extern "C" size_t df_posenet_workspace_bytes(const df_net *h, int B, int H, int W) {
+  if (posenet_args_ok(as_net(h), B, H, W) != DF_OK) return 0;
+  Ctx c{const_cast<Net *>(as_net(h)), nullptr, true, nullptr};
+  PoseNetOut o{};
+  posenet_forward(c, B, H, W, nullptr, nullptr, nullptr, nullptr, o);
+  return c.off;
+}
+
+extern "C" int df_posenet_forward(df_net *h, int B, int H, int W, const float *img, const float *cloud,
+                                  const int64_t *choose, const int64_t *obj, float *out_r, float *out_t, float *out_c,
+                                  float *emb, void *ws, size_t ws_bytes, df_stream_t stream) {
+  int rc = posenet_args_ok(as_net(h), B, H, W);
+  if (rc != DF_OK) return rc;
+  if ((rc = check_ready(*as_net(h))) != DF_OK) return rc;
+  if (!img || !cloud || !choose || !obj || !out_r || !out_t || !out_c || !emb || !ws) return set_error(DF_ERR_ARG, "posenet_forward: null pointer");
+  Ctx c{as_net(h), to_stream(stream), false, static_cast<char *>(ws)};
+  c.cap = ws_bytes;
+  if (df_posenet_workspace_bytes(h, B, H, W) > ws_bytes) return set_error(DF_ERR_WORKSPACE, "posenet_forward: workspace too small");
+  PoseNetOut o{out_r, out_t, out_c, emb};
+  posenet_forward(c, B, H, W, img, cloud, choose, obj, o);
+  return finish(c, "posenet_forward");
+}
+
+static void refiner_standalone(Ctx &c, int B, const float *x, const float *emb, const int64_t *obj, float *out_r, float *out_t) {
+  const int N = c.net->num_points, Npad = round_up(N, 128);
+  float *emb_pm = c.f((size_t)B * Npad * 32);
+  RefinerBufs r = refiner_alloc(c, B, N, Npad);
+  if (c.live()) launch_emb_to_pm(emb, emb_pm, B, N, Npad, c.st);
+  refiner_prepare(c, r, B, Npad, emb_pm);
+  refiner_iterate(c, r, B, N, Npad, x, nullptr, obj, out_r, out_t, nullptr, nullptr, nullptr);
+}
+
+extern "C" size_t df_refiner_workspace_bytes(const df_net *h, int B) {
+  if (!h || as_net(h)->kind != 1 || B <= 0) return 0;
+  Ctx c{const_cast<Net *>(as_net(h)), nullptr, true, nullptr};
+  refiner_standalone(c, B, nullptr, nullptr, nullptr, nullptr, nullptr);
+  return c.off;
+}
+
+extern "C" int df_refiner_forward(df_net *h, int B, const float *x, const float *emb, const int64_t *obj, float *out_r,
+                                  float *out_t, void *ws, size_t ws_bytes, df_stream_t stream) {
+  if (!h || as_net(h)->kind != 1) return set_error(DF_ERR_ARG, "not a PoseRefineNet handle");
+  if (B <= 0) return set_error(DF_ERR_ARG, "refiner_forward: B must be >= 1");
+  int rc = check_ready(*as_net(h));
+  if (rc != DF_OK) return rc;
+  if (!x || !emb || !obj || !out_r || !out_t || !ws) return set_error(DF_ERR_ARG, "refiner_forward: null pointer");
+  if (df_refiner_workspace_bytes(h, B) > ws_bytes) return set_error(DF_ERR_WORKSPACE, "refiner_forward: workspace too small");
+  Ctx c{as_net(h), to_stream(stream), false, static_cast<char *>(ws)};
+  c.cap = ws_bytes;
+  refiner_standalone(c, B, x, emb, obj, out_r, out_t);
+  return finish(c, "refiner_forward");
+}
+
+// PoseNet -> selection -> `iters` refine passes, entirely on the device
+static void estimate(Ctx &cp, Ctx &cr, int B, int H, int W, const float *img, const float *cloud, const int64_t *choose,
+                     const int64_t *obj, int iters, double *pose_wo, double *pose) {
+  const int N = cp.net->num_points, Npad = round_up(N, 128);
+  PoseNetOut o{};
+  o.out_r = cp.f((size_t)B * N * 4); o.out_t = cp.f((size_t)B * N * 3); o.out_c = cp.f((size_t)B * N);
+  o.emb = cp.f((size_t)B * 32 * N);
+  double *state = reinterpret_cast<double *>(cp.bytes((size_t)B * 7 * sizeof(double)));
+  float *rt = cp.f((size_t)B * 12);
+  posenet_forward(cp, B, H, W, img, cloud, choose, obj, o);
+  if (cp.live()) launch_pose_select(o.out_r, o.out_t, o.out_c, cloud, B, N, pose_wo, state, rt, nullptr, cp.st);
+  // the refiner context continues in the same workspace
+  cr.off = cp.off;
+  RefinerBufs r = refiner_alloc(cr, B, N, Npad);
+  if (iters > 0) refiner_prepare(cr, r, B, Npad, o.emb_pm);
+  for (int it = 0; it < iters; ++it)
+    refiner_iterate(cr, r, B, N, Npad, cloud, rt, obj, nullptr, nullptr, state, rt, it == iters - 1 ? pose : nullptr);
+  if (iters == 0 && cp.live() && pose) hipMemcpyAsync(pose, state, (size_t)B * 7 * sizeof(double), hipMemcpyDeviceToDevice, cp.st);
+}
+
+extern "C" size_t df_estimate_workspace_bytes(const df_net *pn, const df_net *rf, int B, int H, int W) {
+  if (posenet_args_ok(as_net(pn), B, H, W) != DF_OK || !rf || as_net(rf)->kind != 1) return 0;
+  Ctx cp{const_cast<Net *>(as_net(pn)), nullptr, true, nullptr}, cr{const_cast<Net *>(as_net(rf)), nullptr, true, nullptr};
+  estimate(cp, cr, B, H, W, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr);
+  return cr.off;
+}
+
+extern "C" int df_estimate_poses(df_net *pn, df_net *rf, int B, int H, int W, const float *img, const float *cloud,
+                                 const int64_t *choose, const int64_t *obj, int iters, double *pose_wo, double *pose,
+                                 void *ws, size_t ws_bytes, df_stream_t stream) {
+  int rc = posenet_args_ok(as_net(pn), B, H, W);
+  if (rc != DF_OK) return rc;
+  if (!rf || as_net(rf)->kind != 1) return set_error(DF_ERR_ARG, "estimate_poses: not a PoseRefineNet handle");
+  if (as_net(rf)->num_points != as_net(pn)->num_points || as_net(rf)->num_obj != as_net(pn)->num_obj)
+    return set_error(DF_ERR_ARG, "estimate_poses: estimator / refiner disagree on num_points or num_obj");
+  if (iters < 0) return set_error(DF_ERR_ARG, "estimate_poses: iters < 0");
+  if ((rc = check_ready(*as_net(pn))) != DF_OK || (rc = check_ready(*as_net(rf))) != DF_OK) return rc;
+  if (!img || !cloud || !choose || !obj || !pose || !ws) return set_error(DF_ERR_ARG, "estimate_poses: null pointer");
+  if (df_estimate_workspace_bytes(pn, rf, B, H, W) > ws_bytes) return set_error(DF_ERR_WORKSPACE, "estimate_poses: workspace too small");
+  Ctx cp{as_net(pn), to_stream(stream), false, static_cast<char *>(ws)}, cr{as_net(rf), to_stream(stream), false, static_cast<char *>(ws)};
+  cp.cap = cr.cap = ws_bytes;
+  estimate(cp, cr, B, H, W, img, cloud, choose, obj, iters, pose_wo, pose);
+  if (cp.err != DF_OK) return cp.err;
+  return finish(cr, "estimate_poses");
+}
+
+extern "C" int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream) {
+  if (!d) return set_error(DF_ERR_ARG, "conv2d_nhwc: null descriptor");
+  if (d->KH != d->KW) return set_error(DF_ERR_ARG, "conv2d_nhwc: square kernels only");
+  if (d->act == ACT_PRELU && !d->prelu) return set_error(DF_ERR_ARG, "conv2d_nhwc: PReLU needs a slope");
+  ConvParams p;
+  p.in = d->in; p.wgt = d->wgt; p.bias = d->bias; p.res = d->res; p.prelu = d->prelu; p.out = d->out;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_ld = d->in_ld; p.in_coff = d->in_coff;
+  p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout; p.out_ld = d->out_ld; p.out_coff = d->out_coff;
+  p.res_ld = d->res_ld; p.res_coff = d->res_coff;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.act = d->act;
+  if (p.OH != conv_out(p.H, p.KH, p.stride, p.pad, p.dil) || p.OW != conv_out(p.W, p.KW, p.stride, p.pad, p.dil))
+    return set_error(DF_ERR_ARG, "conv2d_nhwc: OH/OW do not match the convolution geometry");
+  return launch_conv(p, to_stream(stream));
+}

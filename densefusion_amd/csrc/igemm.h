@@ -1,0 +1,40 @@
+// Implicit-GEMM convolution / batched per-point GEMM on fp32 MFMA (gfx950).
+#pragma once
+#include "common.h"
+
+namespace df {
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_PRELU = 2 };
+
+// out[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias[n] (+ res[m][n]) )
+//   m = (b, oy, ox) over B*OH*OW output pixels (or points), n = output channel,
+//   k = (ky, kx, c): A[m][k] = in[b][oy*stride - pad + ky*dil][ox*stride - pad + kx*dil][c]  (0 outside)
+// Activations are channels-last (NHWC / point-major) fp32; weights are [Cout][KH*KW*Cin] fp32.
+struct ConvParams {
+  const float *in = nullptr;   // [B][H][W][in_ld], channels [in_coff, in_coff + Cin) are consumed
+  const float *wgt = nullptr;  // [Cout][K]
+  const float *bias = nullptr; // [Cout], or [groups][bias_group_ld] when bias_group_ld > 0, or null
+  const float *res = nullptr;  // residual [M][res_ld] (channel offset res_coff) or null
+  const float *prelu = nullptr;  // one shared slope (ACT_PRELU)
+  float *out = nullptr;        // [M][out_ld], written at channel offset out_coff; may be null with colsum
+  float *colsum = nullptr;     // optional [M/BM * WAVES_M][Cout] partial column sums of the activated output
+  int B = 1, H = 1, W = 1, Cin = 0, in_ld = 0, in_coff = 0;
+  int OH = 1, OW = 1, Cout = 0, out_ld = 0, out_coff = 0;
+  int res_ld = 0, res_coff = 0;
+  int KH = 1, KW = 1, stride = 1, pad = 0, dil = 1;
+  int act = ACT_NONE;
+  // row groups (per-object point blocks): rows_per_group > 0 => row m belongs to group m / rows_per_group
+  // and is a real point iff (m % rows_per_group) < rows_valid; used by bias_group_ld and colsum
+  int rows_per_group = 0, rows_valid = 0, bias_group_ld = 0;
+  // blockIdx.z "head" groups (the r/t/c towers): per-z element offsets
+  int zcount = 1;
+  long z_in_coff = 0, z_wgt = 0, z_bias = 0, z_out_coff = 0;
+};
+
+// number of colsum partial rows a launch with these params writes (so callers can size the buffer)
+int conv_colsum_rows(const ConvParams &p);
+// FLOPs (2*MAC) of the launch, algorithmic (no padding)
+double conv_flops(const ConvParams &p);
+int launch_conv(const ConvParams &p, hipStream_t st);
+
+}  // namespace df

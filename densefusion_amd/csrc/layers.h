@@ -1,0 +1,40 @@
+// Memory-bound companion kernels of the DenseFusion forward (channels-last fp32, gfx950).
+#pragma once
+#include "common.h"
+
+namespace df {
+
+// img [B][3][H][W] -> out [B][H][W][4] (4th channel zero) : feeds the 7x7 stem as a Cin=4 implicit GEMM
+void launch_nchw3_to_nhwc4(const float *img, float *out, int B, int H, int W, hipStream_t st);
+// MaxPool2d(3, stride 2, pad 1) on NHWC (lib/extractors.py:84)
+void launch_maxpool3s2(const float *in, float *out, int B, int H, int W, int C, int OH, int OW, hipStream_t st);
+// nn.Upsample(scale_factor=2, bilinear, align_corners=True) on NHWC (lib/pspnet.py:31)
+void launch_upsample2x_ac(const float *in, float *out, int B, int H, int W, int C, hipStream_t st);
+// AdaptiveAvgPool2d(s) for s in {1,2,3,6} (lib/pspnet.py:15-17); in = NHWC rows of width in_ld at channel
+// offset in_coff; out = 4 stage blocks [B*s*s][C] laid back to back (stage offsets 0, B, 5B, 14B rows)
+void launch_psp_pool(const float *in, int in_ld, int in_coff, float *out, int B, int H, int W, int C, hipStream_t st);
+// F.upsample(size=(H,W), bilinear) with align_corners=False of the 4 stage maps into the concat buffer
+// (lib/pspnet.py:22): out[b][y][x][stage*C + c], row width out_ld
+void launch_psp_upsample_concat(const float *stages, float *out, int out_ld, int B, int H, int W, int C, hipStream_t st);
+// final 1x1 conv 64->32 + LogSoftmax over channels (lib/pspnet.py:53-56) evaluated ONLY at the N chosen
+// pixels (lib/network.py:98-102).  feat [B][H*W][64]; choose [B][N] int64; emb [B][32][N] (reference
+// layout, returned to the caller) and emb_pm [B][Npad][32] (point-major, for the MLPs)
+void launch_gather_final_logsoftmax(const float *feat, const int64_t *choose, const float *w, const float *bias,
+                                    float *emb, float *emb_pm, int B, int HW, int N, int Npad, hipStream_t st);
+// emb [B][32][N] -> emb_pm [B][Npad][32]  (PoseRefineNet.forward called on its own)
+void launch_emb_to_pm(const float *emb, float *emb_pm, int B, int N, int Npad, hipStream_t st);
+// Conv1d(3,64,1)+ReLU on the cloud (lib/network.py:54,152); optional rigid pre-transform
+// new = (p - T[b]) . R[b]  (tools/eval_ycb.py:211) with rt [B][12] = R row-major (9) then T (3)
+void launch_cloud_conv1(const float *cloud, const float *rt, const float *w, const float *bias, float *out, int out_ld,
+                        int B, int N, int Npad, hipStream_t st);
+// mean over the points of each object from the GEMM's per-wave partial column sums
+void launch_colsum_finish(const float *partial, int rows_per_obj, float *mean, int B, int C, int N, hipStream_t st);
+// y[b][g*nout + n] = act(sum_k x[b][g*x_gstride + k] * W[g*nout + n][k] + bias[..]) for a handful of rows b
+void launch_linear_rows(const float *x, int x_ld, int x_gstride, const float *w, const float *bias, float *y, int y_ld,
+                        int rows, int K, int nout, int groups, int relu, hipStream_t st);
+// last head layer for the selected object only (lib/network.py:119-131): h3 [B][Npad][384] = r|t|c towers
+void launch_head_final(const float *h3, const float *w_r, const float *b_r, const float *w_t, const float *b_t,
+                       const float *w_c, const float *b_c, const int64_t *obj, int num_obj, float *out_r, float *out_t,
+                       float *out_c, int B, int N, int Npad, hipStream_t st);
+
+}  // namespace df

@@ -1,0 +1,394 @@
+// Memory-bound companion kernels of the DenseFusion forward: layout change, pooling, bilinear
+// resampling, the gather + 1x1 + LogSoftmax tail, tiny per-point layers and row reductions.
+// All tensors fp32, channels-last; 16-byte vector accesses over the channel axis; 64-wide waves.
+#include "layers.h"
+
+namespace df {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int TPB = 256;
+
+inline int blocks_for(long n, int cap = 256 * 32) {
+  long b = (n + TPB - 1) / TPB;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+__global__ __launch_bounds__(TPB) void nchw3_to_nhwc4_kernel(const float *__restrict__ img, float *__restrict__ out,
+                                                             int B, int HW) {
+  const long total = (long)B * HW;
+  for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const long b = i / HW, p = i - b * HW;
+    const float *s = img + b * 3 * HW + p;
+    f32x4 v = {s[0], s[HW], s[2 * (long)HW], 0.f};
+    reinterpret_cast<f32x4 *>(out)[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void maxpool3s2_kernel(const float *__restrict__ in, float *__restrict__ out, int B,
+                                                         int H, int W, int C4, int OH, int OW) {
+  const long total = (long)B * OH * OW * C4;
+  for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const int c = (int)(i % C4);
+    long r = i / C4;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH);
+    const int b = (int)(r / OH);
+    const float ninf = -__builtin_inff();
+    f32x4 m = {ninf, ninf, ninf, ninf};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const f32x4 v = reinterpret_cast<const f32x4 *>(in)[((long)(b * H + iy) * W + ix) * C4 + c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+      }
+    }
+    reinterpret_cast<f32x4 *>(out)[i] = m;
+  }
+}
+
+// bilinear source coordinate helpers (ATen UpSample.h semantics, fp32)
+__device__ inline void src_ac(int dst, float scale, int in_size, int &i0, int &i1, float &l0, float &l1) {
+  const float s = scale * (float)dst;                       // align_corners=True
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+  l0 = 1.f - l1;
+}
+__device__ inline void src_hp(int dst, float scale, int in_size, int &i0, int &i1, float &l0, float &l1) {
+  float s = scale * ((float)dst + 0.5f) - 0.5f;             // align_corners=False (half-pixel), clamped at 0
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+  l0 = 1.f - l1;
+}
+__device__ inline f32x4 lerp4(const f32x4 &v00, const f32x4 &v01, const f32x4 &v10, const f32x4 &v11, float wy0,
+                              float wy1, float wx0, float wx1) {
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = wy0 * (wx0 * v00[e] + wx1 * v01[e]) + wy1 * (wx0 * v10[e] + wx1 * v11[e]);
+  return o;
+}
+
+__global__ __launch_bounds__(TPB) void upsample2x_ac_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                            int B, int H, int W, int C4) {
+  const int OH = 2 * H, OW = 2 * W;
+  const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  const long total = (long)B * OH * OW * C4;
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(in);
+  for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const int c = (int)(i % C4);
+    long r = i / C4;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH);
+    const int b = (int)(r / OH);
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    src_ac(oy, sh, H, y0, y1, wy0, wy1);
+    src_ac(ox, sw, W, x0, x1, wx0, wx1);
+    const long base = (long)b * H * W;
+    const f32x4 v00 = src[(base + (long)y0 * W + x0) * C4 + c], v01 = src[(base + (long)y0 * W + x1) * C4 + c];
+    const f32x4 v10 = src[(base + (long)y1 * W + x0) * C4 + c], v11 = src[(base + (long)y1 * W + x1) * C4 + c];
+    reinterpret_cast<f32x4 *>(out)[i] = lerp4(v00, v01, v10, v11, wy0, wy1, wx0, wx1);
+  }
+}
+
+__device__ inline void psp_bin(int bin, int &s, int &local) {
+  if (bin < 1) { s = 1; local = bin; }
+  else if (bin < 5) { s = 2; local = bin - 1; }
+  else if (bin < 14) { s = 3; local = bin - 5; }
+  else { s = 6; local = bin - 14; }
+}
+__device__ __host__ inline int psp_stage_off(int stage) { return stage == 0 ? 0 : stage == 1 ? 1 : stage == 2 ? 5 : 14; }
+
+// grid (50, B); thread = one float4 of channels
+__global__ __launch_bounds__(128) void psp_pool_kernel(const float *__restrict__ in, int in_ld, int in_coff,
+                                                       float *__restrict__ out, int B, int H, int W, int C) {
+  int s, local;
+  psp_bin(blockIdx.x, s, local);
+  const int b = blockIdx.y;
+  const int i = local / s, j = local - i * s;
+  const int y0 = (i * H) / s, y1 = ((i + 1) * H + s - 1) / s;     // [floor(i*H/s), ceil((i+1)*H/s))
+  const int x0 = (j * W) / s, x1 = ((j + 1) * W + s - 1) / s;
+  const float cnt = (float)((y1 - y0) * (x1 - x0));
+  const int stage = s == 1 ? 0 : s == 2 ? 1 : s == 3 ? 2 : 3;
+  float *dst = out + ((size_t)psp_stage_off(stage) * B + (size_t)b * s * s + local) * C;
+  for (int c = threadIdx.x * 4; c < C; c += 128 * 4) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(in + ((size_t)(b * H + y) * W + x) * in_ld + in_coff + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+      }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = acc[e] / cnt;
+    *reinterpret_cast<f32x4 *>(dst + c) = acc;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void psp_upsample_concat_kernel(const float *__restrict__ stages,
+                                                                  float *__restrict__ out, int out_ld, int B, int H,
+                                                                  int W, int C) {
+  const int C4 = C / 4;
+  const long total = (long)B * H * W * 4 * C4;
+  for (long idx = blockIdx.x * (long)TPB + threadIdx.x; idx < total; idx += (long)gridDim.x * TPB) {
+    const int c = (int)(idx % C4);
+    long r = idx / C4;
+    const int stage = (int)(r % 4); r /= 4;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    const int s = stage == 0 ? 1 : stage == 1 ? 2 : stage == 2 ? 3 : 6;
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    src_hp(y, (float)s / (float)H, s, y0, y1, wy0, wy1);
+    src_hp(x, (float)s / (float)W, s, x0, x1, wx0, wx1);
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(stages + ((size_t)psp_stage_off(stage) * B + (size_t)b * s * s) * C);
+    const f32x4 v00 = src[(y0 * s + x0) * C4 + c], v01 = src[(y0 * s + x1) * C4 + c];
+    const f32x4 v10 = src[(y1 * s + x0) * C4 + c], v11 = src[(y1 * s + x1) * C4 + c];
+    *reinterpret_cast<f32x4 *>(out + ((size_t)(b * H + y) * W + x) * out_ld + stage * C + c * 4) =
+        lerp4(v00, v01, v10, v11, wy0, wy1, wx0, wx1);
+  }
+}
+
+// 8 points per workgroup pass: each 32-lane half-wave owns one point, lane = output channel.
+__global__ __launch_bounds__(TPB) void gather_final_lsm_kernel(const float *__restrict__ feat,
+                                                               const int64_t *__restrict__ choose,
+                                                               const float *__restrict__ w, const float *__restrict__ bias,
+                                                               float *__restrict__ emb, float *__restrict__ emb_pm, int B,
+                                                               int HW, int N, int Npad) {
+  __shared__ __attribute__((aligned(16))) float sx[8][64];
+  const int tid = threadIdx.x;
+  const int o = tid & 31, slot = tid >> 5;
+  float wr[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) wr[c] = w[o * 64 + c];
+  const float bo = bias[o];
+  const long total = (long)B * N;
+  for (long p0 = (long)blockIdx.x * 8; p0 < total; p0 += (long)gridDim.x * 8) {
+    {   // stage the 8 gathered 64-channel pixels: thread t loads 2 floats of point t/32
+      const long p = p0 + slot;
+      float2 v = make_float2(0.f, 0.f);
+      if (p < total) {
+        const long b = p / N;
+        long pix = choose[p];
+        pix = pix < 0 ? 0 : (pix >= HW ? HW - 1 : pix);     // torch.gather would raise; clamp keeps the launch safe
+        v = *reinterpret_cast<const float2 *>(feat + ((size_t)b * HW + pix) * 64 + o * 2);
+      }
+      *reinterpret_cast<float2 *>(&sx[slot][o * 2]) = v;
+    }
+    __syncthreads();
+    float acc = bo;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) acc = __builtin_fmaf(sx[slot][c], wr[c], acc);
+    // LogSoftmax over the 32 channels of this half-wave (lib/pspnet.py:55, implicit dim=1)
+    float mx = acc;
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) { const float t = __shfl_xor(mx, d); mx = t > mx ? t : mx; }
+    const float sh = acc - mx;
+    float se = expf(sh);
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) se += __shfl_xor(se, d);
+    const float r = sh - logf(se);
+    const long p = p0 + slot;
+    if (p < total) {
+      const long b = p / N, n = p - b * N;
+      emb[((size_t)b * 32 + o) * N + n] = r;
+      emb_pm[((size_t)b * Npad + n) * 32 + o] = r;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(TPB) void emb_to_pm_kernel(const float *__restrict__ emb, float *__restrict__ emb_pm, int B,
+                                                        int N, int Npad) {
+  const long total = (long)B * N * 32;
+  for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const int o = (int)(i & 31);
+    const long p = i >> 5;
+    const long b = p / N, n = p - b * N;
+    emb_pm[((size_t)b * Npad + n) * 32 + o] = emb[((size_t)b * 32 + o) * N + n];
+  }
+}
+
+// thread = (point, group of 4 output channels)
+__global__ __launch_bounds__(TPB) void cloud_conv1_kernel(const float *__restrict__ cloud, const float *__restrict__ rt,
+                                                          const float *__restrict__ w, const float *__restrict__ bias,
+                                                          float *__restrict__ out, int out_ld, int B, int N, int Npad) {
+  const long total = (long)B * N * 16;
+  for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const int g = (int)(i & 15);
+    const long p = i >> 4;
+    const long b = p / N, n = p - b * N;
+    float x = cloud[p * 3 + 0], y = cloud[p * 3 + 1], z = cloud[p * 3 + 2];
+    if (rt) {   // new = (p - T) . R   (1x3 times 3x3, tools/eval_ycb.py:211)
+      const float *R = rt + b * 12, *T = R + 9;
+      const float dx = x - T[0], dy = y - T[1], dz = z - T[2];
+      x = dx * R[0] + dy * R[3] + dz * R[6];
+      y = dx * R[1] + dy * R[4] + dz * R[7];
+      z = dx * R[2] + dy * R[5] + dz * R[8];
+    }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = g * 4 + e;
+      float v = bias[c] + w[c * 3 + 0] * x + w[c * 3 + 1] * y + w[c * 3 + 2] * z;
+      o[e] = v > 0.f ? v : 0.f;
+    }
+    *reinterpret_cast<f32x4 *>(out + ((size_t)b * Npad + n) * out_ld + g * 4) = o;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void colsum_finish_kernel(const float *__restrict__ partial, int rows_per_obj,
+                                                            float *__restrict__ mean, int B, int C, int N) {
+  const long total = (long)B * C;
+  for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const long b = i / C, c = i - b * C;
+    float s = 0.f;
+    for (int r = 0; r < rows_per_obj; ++r) s += partial[((size_t)b * rows_per_obj + r) * C + c];
+    mean[i] = s / (float)N;
+  }
+}
+
+// one wave per output column, 8 rows at a time
+__global__ __launch_bounds__(TPB) void linear_rows_kernel(const float *__restrict__ x, int x_ld, int x_gstride,
+                                                          const float *__restrict__ w, const float *__restrict__ bias,
+                                                          float *__restrict__ y, int y_ld, int rows, int K, int nout,
+                                                          int groups, int relu) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+  if (col >= nout * groups) return;
+  const int g = col / nout;
+  const f32x4 *wr = reinterpret_cast<const f32x4 *>(w + (size_t)col * K);
+  const int K4 = K >> 2;
+  for (int r0 = 0; r0 < rows; r0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+    for (int k4 = lane; k4 < K4; k4 += 64) {
+      const f32x4 wv = wr[k4];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if (r0 + r < rows) {
+          const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + (size_t)(r0 + r) * x_ld + g * x_gstride + k4 * 4);
+          acc[r] += (wv[0] * xv[0] + wv[1] * xv[1]) + (wv[2] * xv[2] + wv[3] * xv[3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) acc[r] += __shfl_xor(acc[r], d);
+    }
+    if (lane == 0) {
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (r0 + r < rows) {
+          float v = acc[r] + bv;
+          if (relu) v = v > 0.f ? v : 0.f;
+          y[(size_t)(r0 + r) * y_ld + col] = v;
+        }
+    }
+  }
+}
+
+// thread = (point, output j): j 0-3 quaternion, 4-6 translation, 7 confidence (sigmoid)
+__global__ __launch_bounds__(TPB) void head_final_kernel(const float *__restrict__ h3, const float *__restrict__ w_r,
+                                                         const float *__restrict__ b_r, const float *__restrict__ w_t,
+                                                         const float *__restrict__ b_t, const float *__restrict__ w_c,
+                                                         const float *__restrict__ b_c, const int64_t *__restrict__ obj,
+                                                         int num_obj, float *__restrict__ out_r,
+                                                         float *__restrict__ out_t, float *__restrict__ out_c, int B,
+                                                         int N, int Npad) {
+  const long total = (long)B * N * 8;
+  for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const int j = (int)(i & 7);
+    const long p = i >> 3;
+    const long b = p / N, n = p - b * N;
+    long o = obj[b];
+    o = o < 0 ? 0 : (o >= num_obj ? num_obj - 1 : o);
+    const float *wrow;
+    float bv;
+    int slice;
+    if (j < 4) { wrow = w_r + (o * 4 + j) * 128; bv = b_r[o * 4 + j]; slice = 0; }
+    else if (j < 7) { wrow = w_t + (o * 3 + (j - 4)) * 128; bv = b_t[o * 3 + (j - 4)]; slice = 128; }
+    else { wrow = w_c + o * 128; bv = b_c[o]; slice = 256; }
+    const f32x4 *xv = reinterpret_cast<const f32x4 *>(h3 + ((size_t)b * Npad + n) * 384 + slice);
+    const f32x4 *wv = reinterpret_cast<const f32x4 *>(wrow);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const f32x4 a = xv[k], c = wv[k];
+      acc += (a[0] * c[0] + a[1] * c[1]) + (a[2] * c[2] + a[3] * c[3]);
+    }
+    acc += bv;
+    if (j < 4) out_r[p * 4 + j] = acc;
+    else if (j < 7) out_t[p * 3 + (j - 4)] = acc;
+    else out_c[p] = 1.f / (1.f + expf(-acc));
+  }
+}
+
+}  // namespace
+
+void launch_nchw3_to_nhwc4(const float *img, float *out, int B, int H, int W, hipStream_t st) {
+  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(blocks_for((long)B * H * W)), dim3(TPB), 0, st, img, out, B, H * W);
+}
+void launch_maxpool3s2(const float *in, float *out, int B, int H, int W, int C, int OH, int OW, hipStream_t st) {
+  hipLaunchKernelGGL(maxpool3s2_kernel, dim3(blocks_for((long)B * OH * OW * (C / 4))), dim3(TPB), 0, st, in, out, B, H, W,
+                     C / 4, OH, OW);
+}
+void launch_upsample2x_ac(const float *in, float *out, int B, int H, int W, int C, hipStream_t st) {
+  hipLaunchKernelGGL(upsample2x_ac_kernel, dim3(blocks_for((long)B * 4 * H * W * (C / 4))), dim3(TPB), 0, st, in, out, B,
+                     H, W, C / 4);
+}
+void launch_psp_pool(const float *in, int in_ld, int in_coff, float *out, int B, int H, int W, int C, hipStream_t st) {
+  hipLaunchKernelGGL(psp_pool_kernel, dim3(50, B), dim3(128), 0, st, in, in_ld, in_coff, out, B, H, W, C);
+}
+void launch_psp_upsample_concat(const float *stages, float *out, int out_ld, int B, int H, int W, int C, hipStream_t st) {
+  hipLaunchKernelGGL(psp_upsample_concat_kernel, dim3(blocks_for((long)B * H * W * C)), dim3(TPB), 0, st, stages, out,
+                     out_ld, B, H, W, C);
+}
+void launch_gather_final_logsoftmax(const float *feat, const int64_t *choose, const float *w, const float *bias,
+                                    float *emb, float *emb_pm, int B, int HW, int N, int Npad, hipStream_t st) {
+  hipLaunchKernelGGL(gather_final_lsm_kernel, dim3(blocks_for((long)B * N * 32)), dim3(TPB), 0, st, feat, choose, w, bias,
+                     emb, emb_pm, B, HW, N, Npad);
+}
+void launch_emb_to_pm(const float *emb, float *emb_pm, int B, int N, int Npad, hipStream_t st) {
+  hipLaunchKernelGGL(emb_to_pm_kernel, dim3(blocks_for((long)B * N * 32)), dim3(TPB), 0, st, emb, emb_pm, B, N, Npad);
+}
+void launch_cloud_conv1(const float *cloud, const float *rt, const float *w, const float *bias, float *out, int out_ld,
+                        int B, int N, int Npad, hipStream_t st) {
+  hipLaunchKernelGGL(cloud_conv1_kernel, dim3(blocks_for((long)B * N * 16)), dim3(TPB), 0, st, cloud, rt, w, bias, out,
+                     out_ld, B, N, Npad);
+}
+void launch_colsum_finish(const float *partial, int rows_per_obj, float *mean, int B, int C, int N, hipStream_t st) {
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(blocks_for((long)B * C)), dim3(TPB), 0, st, partial, rows_per_obj, mean,
+                     B, C, N);
+}
+void launch_linear_rows(const float *x, int x_ld, int x_gstride, const float *w, const float *bias, float *y, int y_ld,
+                        int rows, int K, int nout, int groups, int relu, hipStream_t st) {
+  hipLaunchKernelGGL(linear_rows_kernel, dim3((nout * groups + 3) / 4), dim3(TPB), 0, st, x, x_ld, x_gstride, w, bias, y,
+                     y_ld, rows, K, nout, groups, relu);
+}
+void launch_head_final(const float *h3, const float *w_r, const float *b_r, const float *w_t, const float *b_t,
+                       const float *w_c, const float *b_c, const int64_t *obj, int num_obj, float *out_r, float *out_t,
+                       float *out_c, int B, int N, int Npad, hipStream_t st) {
+  hipLaunchKernelGGL(head_final_kernel, dim3(blocks_for((long)B * N * 8)), dim3(TPB), 0, st, h3, w_r, b_r, w_t, b_t, w_c,
+                     b_c, obj, num_obj, out_r, out_t, out_c, B, N, Npad);
+}
+
+}  // namespace df

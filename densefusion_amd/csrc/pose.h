@@ -1,0 +1,18 @@
+// On-device pose selection / composition (fp64), see pose.hip.
+#pragma once
+#include "common.h"
+
+namespace df {
+
+// per object: arg-max confidence, normalised quaternion + (point + offset) there -> state[B][7] (fp64),
+// optional copy pose_wo[B][7], the fp32 R|T record rt[B][12] for the first refine pass, optional which[B]
+void launch_pose_select(const float *out_r, const float *out_t, const float *out_c, const float *cloud, int B, int N,
+                        double *pose_wo, double *state, float *rt, int *which, hipStream_t st);
+
+// per object: refiner conv3_r/conv3_t rows of the selected object on f2 [B][256] (r|t towers), raw outputs to
+// out_r[B][4] / out_t[B][3] when non-null; when state != null also compose into state and refresh rt
+void launch_refiner_tail(const float *f2, const float *w_r, const float *b_r, const float *w_t, const float *b_t,
+                         const int64_t *obj, int num_obj, float *out_r, float *out_t, double *state, float *rt,
+                         double *pose_out, int B, hipStream_t st);
+
+}  // namespace df

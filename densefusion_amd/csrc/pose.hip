@@ -1,0 +1,171 @@
+// On-device pose algebra of the eval loops, so the refine loop never returns to the host.
+//
+// The reference does this part in numpy float64 on the host with one D2H sync per step
+// (tools/eval_ycb.py:193-229, tools/eval_linemod.py:82-114).  Here one tiny workgroup per object does
+// the same arithmetic in fp64 on the GPU: per-pixel pose selection (arg-max confidence), quaternion ->
+// rotation (lib/transformations.py:1266-1278), 4x4 composition and rotation -> quaternion
+// (lib/transformations.py:1320-1341,1361-1363), and hands the fp32 R|T the next refiner pass needs
+// to the cloud kernel through a 12-float record per object.
+#include "pose.h"
+
+namespace df {
+namespace {
+
+constexpr double QEPS = 2.220446049250313e-16 * 4.0;   // numpy.finfo(float).eps * 4 (transformations.py:1893)
+
+// lib/transformations.py:1266-1278 ; M is 3x3 row-major
+__device__ void quat_to_mat(const double qin[4], double M[9]) {
+  double q[4] = {qin[0], qin[1], qin[2], qin[3]};
+  const double n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (n < QEPS) {
+    M[0] = 1; M[1] = 0; M[2] = 0; M[3] = 0; M[4] = 1; M[5] = 0; M[6] = 0; M[7] = 0; M[8] = 1;
+    return;
+  }
+  const double s = sqrt(2.0 / n);
+  for (int i = 0; i < 4; ++i) q[i] *= s;
+  double o[4][4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) o[i][j] = q[i] * q[j];
+  M[0] = 1.0 - o[2][2] - o[3][3]; M[1] = o[1][2] - o[3][0];       M[2] = o[1][3] + o[2][0];
+  M[3] = o[1][2] + o[3][0];       M[4] = 1.0 - o[1][1] - o[3][3]; M[5] = o[2][3] - o[1][0];
+  M[6] = o[1][3] - o[2][0];       M[7] = o[2][3] + o[1][0];       M[8] = 1.0 - o[1][1] - o[2][2];
+}
+
+// lib/transformations.py:1320-1341 (isprecise=True; homogeneous M[3][3] == 1) + sign rule :1361-1363
+__device__ void mat_to_quat_precise(const double M[9], double q[4]) {
+  const double m33 = 1.0;
+  double t = M[0] + M[4] + M[8] + m33;
+  if (t > m33) {
+    q[0] = t;
+    q[3] = M[3] - M[1];
+    q[2] = M[2] - M[6];
+    q[1] = M[7] - M[5];
+  } else {
+    int i = 0, j = 1, k = 2;
+    if (M[4] > M[0]) { i = 1; j = 2; k = 0; }
+    if (M[8] > M[i * 3 + i]) { i = 2; j = 0; k = 1; }
+    t = M[i * 3 + i] - (M[j * 3 + j] + M[k * 3 + k]) + m33;
+    double p[4];
+    p[i] = t;
+    p[j] = M[i * 3 + j] + M[j * 3 + i];
+    p[k] = M[k * 3 + i] + M[i * 3 + k];
+    p[3] = M[k * 3 + j] - M[j * 3 + k];
+    q[0] = p[3]; q[1] = p[0]; q[2] = p[1]; q[3] = p[2];
+  }
+  const double s = 0.5 / sqrt(t * m33);
+  for (int e = 0; e < 4; ++e) q[e] *= s;
+  if (q[0] < 0.0)
+    for (int e = 0; e < 4; ++e) q[e] = -q[e];
+}
+
+// R (fp64) and t -> the fp32 record the refiner's cloud kernel reads (eval_ycb.py:206-209 casts)
+__device__ void write_rt(const double M[9], const double t[3], float *rt) {
+  for (int e = 0; e < 9; ++e) rt[e] = (float)M[e];
+  for (int e = 0; e < 3; ++e) rt[9 + e] = (float)t[e];
+}
+
+// one workgroup per object: arg-max confidence (first maximum wins, like torch.max), normalised quat and
+// points+offset at that pixel (eval_ycb.py:193-203)
+__global__ __launch_bounds__(256) void pose_select_kernel(const float *__restrict__ out_r, const float *__restrict__ out_t,
+                                                          const float *__restrict__ out_c, const float *__restrict__ cloud,
+                                                          int N, double *__restrict__ pose_wo, double *__restrict__ state,
+                                                          float *__restrict__ rt, int *__restrict__ which) {
+  __shared__ float s_v[256];
+  __shared__ int s_i[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float best = -__builtin_inff();
+  int bi = 0x7fffffff;
+  for (int n = tid; n < N; n += 256) {
+    const float c = out_c[(size_t)b * N + n];
+    if (c > best) { best = c; bi = n; }       // ascending n per thread: first maximum kept
+  }
+  s_v[tid] = best; s_i[tid] = bi;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (tid < d) {
+      const float ov = s_v[tid + d];
+      const int oi = s_i[tid + d];
+      if (ov > s_v[tid] || (ov == s_v[tid] && oi < s_i[tid])) { s_v[tid] = ov; s_i[tid] = oi; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int wm = s_i[0];
+    if (wm < 0 || wm >= N) wm = 0;             // all-NaN confidences
+    const float *q = out_r + ((size_t)b * N + wm) * 4;
+    const float nrm = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    double st[7];
+    for (int e = 0; e < 4; ++e) st[e] = (double)(q[e] / nrm);
+    for (int e = 0; e < 3; ++e)
+      st[4 + e] = (double)(cloud[((size_t)b * N + wm) * 3 + e] + out_t[((size_t)b * N + wm) * 3 + e]);
+    for (int e = 0; e < 7; ++e) {
+      state[b * 7 + e] = st[e];
+      if (pose_wo) pose_wo[b * 7 + e] = st[e];
+    }
+    double M[9];
+    quat_to_mat(st, M);
+    write_rt(M, st + 4, rt + b * 12);
+    if (which) which[b] = wm;
+  }
+}
+
+// one wave per object: last refiner layer for the selected object (lib/network.py:198-204), then
+// normalise, compose with the running pose and refresh R|T (eval_ycb.py:213-229)
+__global__ __launch_bounds__(64) void refiner_tail_kernel(const float *__restrict__ f2, const float *__restrict__ w_r,
+                                                          const float *__restrict__ b_r, const float *__restrict__ w_t,
+                                                          const float *__restrict__ b_t, const int64_t *__restrict__ obj,
+                                                          int num_obj, float *__restrict__ out_r, float *__restrict__ out_t,
+                                                          double *__restrict__ state, float *__restrict__ rt,
+                                                          double *__restrict__ pose_out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  long o = obj[b];
+  o = o < 0 ? 0 : (o >= num_obj ? num_obj - 1 : o);
+  float y[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const float *w = j < 4 ? w_r + (o * 4 + j) * 128 : w_t + (o * 3 + (j - 4)) * 128;
+    const float *x = f2 + (size_t)b * 256 + (j < 4 ? 0 : 128);
+    float acc = x[lane] * w[lane] + x[lane + 64] * w[lane + 64];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    y[j] = acc + (j < 4 ? b_r[o * 4 + j] : b_t[o * 3 + (j - 4)]);
+  }
+  if (lane != 0) return;
+  if (out_r) for (int e = 0; e < 4; ++e) out_r[b * 4 + e] = y[e];
+  if (out_t) for (int e = 0; e < 3; ++e) out_t[b * 3 + e] = y[4 + e];
+  if (!state) return;
+  const float nrm = sqrtf(y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3]);
+  double q2[4], t2[3], M1[9], M2[9], Mf[9], tf[3], qf[4];
+  for (int e = 0; e < 4; ++e) q2[e] = (double)(y[e] / nrm);
+  for (int e = 0; e < 3; ++e) t2[e] = (double)y[4 + e];
+  double *st = state + b * 7;
+  quat_to_mat(st, M1);
+  quat_to_mat(q2, M2);
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) Mf[i * 3 + j] = M1[i * 3 + 0] * M2[0 * 3 + j] + M1[i * 3 + 1] * M2[1 * 3 + j] + M1[i * 3 + 2] * M2[2 * 3 + j];
+    tf[i] = M1[i * 3 + 0] * t2[0] + M1[i * 3 + 1] * t2[1] + M1[i * 3 + 2] * t2[2] + st[4 + i];
+  }
+  mat_to_quat_precise(Mf, qf);
+  for (int e = 0; e < 4; ++e) st[e] = qf[e];
+  for (int e = 0; e < 3; ++e) st[4 + e] = tf[e];
+  if (pose_out) for (int e = 0; e < 7; ++e) pose_out[b * 7 + e] = st[e];
+  double Mn[9];
+  quat_to_mat(st, Mn);
+  write_rt(Mn, st + 4, rt + b * 12);
+}
+
+}  // namespace
+
+void launch_pose_select(const float *out_r, const float *out_t, const float *out_c, const float *cloud, int B, int N,
+                        double *pose_wo, double *state, float *rt, int *which, hipStream_t st) {
+  hipLaunchKernelGGL(pose_select_kernel, dim3(B), dim3(256), 0, st, out_r, out_t, out_c, cloud, N, pose_wo, state, rt, which);
+}
+
+void launch_refiner_tail(const float *f2, const float *w_r, const float *b_r, const float *w_t, const float *b_t,
+                         const int64_t *obj, int num_obj, float *out_r, float *out_t, double *state, float *rt,
+                         double *pose_out, int B, hipStream_t st) {
+  hipLaunchKernelGGL(refiner_tail_kernel, dim3(B), dim3(64), 0, st, f2, w_r, b_r, w_t, b_t, obj, num_obj, out_r, out_t,
+                     state, rt, pose_out);
+}
+
+}  // namespace df

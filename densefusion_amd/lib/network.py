@@ -1,0 +1,214 @@
+"""``PoseNet`` / ``PoseRefineNet`` -- host-side mirrors of the reference modules (lib/network.py:70-132,
+170-206) over the HIP engine in libdfusion_hip.so.
+
+What is kept from the reference: class names, constructor arguments, positional ``forward``
+signatures, output shapes, ``.cuda()/.eval()/.parameters()/.state_dict()/.load_state_dict()``
+and the exact checkpoint key/shape layout (77 tensors for PoseNet, 24 for the refiner), so
+``estimator.load_state_dict(torch.load(path))`` works on a reference checkpoint.
+
+What is different: there is no module tree of nn.Conv layers -- parameters are plain
+``nn.Parameter`` leaves registered under the reference's keys, and ``forward`` hands device
+pointers to the C ABI (include/dfusion.h).  The reference evaluates batch element 0 only
+(``b = 0``, network.py:123,202); here a leading batch of B same-sized objects is evaluated
+independently and all B results are returned (B = 1 reproduces the reference shapes).
+Inference only for now: ``forward`` in ``train()`` mode raises (Dropout2d + backward kernels are
+not part of this round).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..synth import posenet_spec, refiner_spec
+
+
+class _Leaf(nn.Module):
+    """Anonymous container so dotted checkpoint keys map onto a module tree."""
+
+
+class _EngineModule(nn.Module):
+    _kind = None  # "posenet" | "refiner"
+
+    def __init__(self, num_points, num_obj):
+        super().__init__()
+        self.num_points = int(num_points)
+        self.num_obj = int(num_obj)
+        self._spec = posenet_spec(self.num_obj) if self._kind == "posenet" else refiner_spec(self.num_obj)
+        gen = torch.Generator().manual_seed(0)
+        for key, shape in self._spec:
+            parts = key.split(".")
+            mod = self
+            for p in parts[:-1]:
+                if not hasattr(mod, p):
+                    mod.add_module(p, _Leaf())
+                mod = getattr(mod, p)
+            if key.endswith(".conv.2.weight"):
+                t = torch.full(shape, 0.25)                      # nn.PReLU default
+            elif key.endswith(".bias"):
+                t = torch.zeros(shape)
+            else:
+                fan_in = int(math.prod(shape[1:])) or 1
+                t = torch.randn(shape, generator=gen) * math.sqrt(2.0 / fan_in)
+            mod.register_parameter(parts[-1], nn.Parameter(t))
+        self._handle = None
+        self._handle_dev = None
+        self._uploaded = {}          # key -> (data_ptr, version)
+        self._ws = None
+
+    # -- engine handle ---------------------------------------------------------------------------
+    def _engine(self, device):
+        L = _lib.lib()
+        if self._handle is None or self._handle_dev != device:
+            self._release()
+            with torch.cuda.device(device):
+                create = L.df_posenet_create if self._kind == "posenet" else L.df_refiner_create
+                self._handle = create(self.num_points, self.num_obj)
+            if not self._handle:
+                _lib.check(-1, "create")
+            self._handle_dev = device
+            self._uploaded = {}
+        for key, p in self.named_parameters():
+            if p.device != device:
+                raise RuntimeError(f"parameter {key} is on {p.device}, input on {device}: call .cuda() first")
+            tag = (p.data_ptr(), p._version)
+            if self._uploaded.get(key) != tag:
+                src = p.detach()
+                if src.dtype != torch.float32 or not src.is_contiguous():
+                    src = src.float().contiguous()
+                _lib.check(L.df_net_load_param(self._handle, key.encode(), src.data_ptr(), src.numel()), f"load_param({key})")
+                self._uploaded[key] = tag
+        return self._handle
+
+    def _release(self):
+        if getattr(self, "_handle", None):
+            _lib.lib().df_net_destroy(self._handle)
+        self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self._ws
+
+    def _check_mode(self):
+        if self.training:
+            raise RuntimeError(f"{type(self).__name__}: only eval() mode is implemented on the HIP path "
+                               "(call .eval(); the training path is not part of this round)")
+
+
+def _dev_f32(t, device=None):
+    if not t.is_cuda:
+        raise RuntimeError("densefusion_amd needs device tensors (no CPU path): call .cuda() on the inputs")
+    return t.detach().float().contiguous()
+
+
+class PoseNet(_EngineModule):
+    """``PoseNet(num_points, num_obj)`` (lib/network.py:70-93)."""
+    _kind = "posenet"
+
+    def forward(self, img, x, choose, obj):
+        """img [B,3,H,W], x [B,N,3], choose [B,1,N]|[B,N] int64, obj [B,1]|[B] int64 ->
+        (out_rx [B,N,4], out_tx [B,N,3], out_cx [B,N,1], emb [B,32,N])   (lib/network.py:95-132)."""
+        self._check_mode()
+        img, x = _dev_f32(img), _dev_f32(x)
+        dev = img.device
+        B, C, H, W = img.shape
+        N = self.num_points
+        if C != 3 or x.shape != (B, N, 3):
+            raise RuntimeError(f"PoseNet.forward: expected img [B,3,H,W] and x [B,{N},3], got {tuple(img.shape)}, {tuple(x.shape)}")
+        choose = choose.to(device=dev, dtype=torch.int64).reshape(B, N).contiguous()
+        obj = obj.to(device=dev, dtype=torch.int64).reshape(B).contiguous()
+        out_r = torch.empty(B, N, 4, device=dev)
+        out_t = torch.empty(B, N, 3, device=dev)
+        out_c = torch.empty(B, N, 1, device=dev)
+        emb = torch.empty(B, 32, N, device=dev)
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            h = self._engine(dev)
+            need = L.df_posenet_workspace_bytes(h, B, H, W)
+            if need == 0:
+                _lib.check(-1, "posenet_workspace_bytes")
+            ws = self._workspace(need, dev)
+            st = L.df_posenet_forward(h, B, H, W, img.data_ptr(), x.data_ptr(), choose.data_ptr(), obj.data_ptr(),
+                                      out_r.data_ptr(), out_t.data_ptr(), out_c.data_ptr(), emb.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), _lib.current_stream())
+        _lib.check(st, "posenet_forward")
+        return out_r, out_t, out_c, emb
+
+
+class PoseRefineNet(_EngineModule):
+    """``PoseRefineNet(num_points, num_obj)`` (lib/network.py:170-185)."""
+    _kind = "refiner"
+
+    def forward(self, x, emb, obj):
+        """x [B,N,3], emb [B,32,N], obj [B,1]|[B] -> (out_rx [B,4], out_tx [B,3])   (lib/network.py:187-206)."""
+        self._check_mode()
+        x, emb = _dev_f32(x), _dev_f32(emb)
+        dev = x.device
+        B, N = x.shape[0], self.num_points
+        if x.shape != (B, N, 3) or emb.shape != (B, 32, N):
+            raise RuntimeError(f"PoseRefineNet.forward: expected x [B,{N},3], emb [B,32,{N}], got {tuple(x.shape)}, {tuple(emb.shape)}")
+        obj = obj.to(device=dev, dtype=torch.int64).reshape(B).contiguous()
+        out_r = torch.empty(B, 4, device=dev)
+        out_t = torch.empty(B, 3, device=dev)
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            h = self._engine(dev)
+            need = L.df_refiner_workspace_bytes(h, B)
+            ws = self._workspace(need, dev)
+            st = L.df_refiner_forward(h, B, x.data_ptr(), emb.data_ptr(), obj.data_ptr(), out_r.data_ptr(),
+                                      out_t.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream())
+        _lib.check(st, "refiner_forward")
+        return out_r, out_t
+
+
+class PoseEstimator:
+    """The inner loop of tools/eval_ycb.py:192-229 as one device-side call (no host round trips).
+
+    ``estimate(img, cloud, choose, obj, iteration)`` -> (pose_wo_refine [B,7] f64, pose [B,7] f64);
+    each row is quaternion (w,x,y,z) then translation -- what the reference appends to
+    ``my_result_wo_refine`` / ``my_result``.
+    """
+
+    def __init__(self, estimator: PoseNet, refiner: PoseRefineNet):
+        self.estimator, self.refiner = estimator, refiner
+        self._ws = None
+
+    def workspace_bytes(self, B, H, W, device):
+        L = _lib.lib()
+        with torch.cuda.device(device):
+            return L.df_estimate_workspace_bytes(self.estimator._engine(device), self.refiner._engine(device), B, H, W)
+
+    def estimate(self, img, cloud, choose, obj, iteration, out=None):
+        self.estimator._check_mode(); self.refiner._check_mode()
+        img, cloud = _dev_f32(img), _dev_f32(cloud)
+        dev = img.device
+        B, _, H, W = img.shape
+        N = self.estimator.num_points
+        choose = choose.to(device=dev, dtype=torch.int64).reshape(B, N).contiguous()
+        obj = obj.to(device=dev, dtype=torch.int64).reshape(B).contiguous()
+        if out is None:
+            out = (torch.empty(B, 7, dtype=torch.float64, device=dev), torch.empty(B, 7, dtype=torch.float64, device=dev))
+        pose_wo, pose = out
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            hp, hr = self.estimator._engine(dev), self.refiner._engine(dev)
+            need = L.df_estimate_workspace_bytes(hp, hr, B, H, W)
+            if need == 0:
+                _lib.check(-1, "estimate_workspace_bytes")
+            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+                self._ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+            st = L.df_estimate_poses(hp, hr, B, H, W, img.data_ptr(), cloud.data_ptr(), choose.data_ptr(), obj.data_ptr(),
+                                     int(iteration), pose_wo.data_ptr(), pose.data_ptr(), self._ws.data_ptr(),
+                                     self._ws.numel(), _lib.current_stream())
+        _lib.check(st, "estimate_poses")
+        return pose_wo, pose

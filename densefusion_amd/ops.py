@@ -1,0 +1,35 @@
+"""Single-layer entry points over the C ABI (unit parity tests, ad-hoc use)."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def conv2d_nhwc(x, w, bias=None, stride=1, pad=0, dil=1, act=0, res=None, prelu=None, out=None, out_coff=0,
+                in_coff=0, cin=None):
+    """Channels-last convolution on the fp32 matrix cores.
+
+    x [B,H,W,ld] (channels [in_coff, in_coff+cin) used); w [Cout,KH,KW,Cin]; returns out [B,OH,OW,out_ld].
+    """
+    B, H, W, in_ld = x.shape
+    Cout, KH, KW, Cin = w.shape
+    cin = Cin if cin is None else cin
+    OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    if out is None:
+        out = torch.empty(B, OH, OW, Cout, device=x.device, dtype=torch.float32)
+    d = _lib.ConvDesc()
+    d.in_, d.wgt, d.out = _lib.dptr(x), _lib.dptr(w), _lib.dptr(out)
+    d.bias = _lib.dptr(bias) if bias is not None else None
+    d.res = _lib.dptr(res) if res is not None else None
+    d.prelu = _lib.dptr(prelu) if prelu is not None else None
+    d.B, d.H, d.W, d.Cin, d.in_ld, d.in_coff = B, H, W, cin, in_ld, in_coff
+    d.OH, d.OW, d.Cout, d.out_ld, d.out_coff = OH, OW, Cout, out.shape[-1], out_coff
+    d.res_ld, d.res_coff = (res.shape[-1] if res is not None else 0), 0
+    d.KH, d.KW, d.stride, d.pad, d.dil, d.act = KH, KW, stride, pad, dil, act
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().df_conv2d_nhwc(ctypes.byref(d), _lib.current_stream()), "conv2d_nhwc")
+    return out

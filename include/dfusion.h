@@ -50,6 +50,78 @@ int df_knn_device(const float *ref_dev, int ref_nb, const float *query_dev, int 
 int df_knn(const float *ref, const float *query, int64_t *idx, int batch, int dim, int ref_nb, int query_nb,
            int k, df_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Network handles (replace the nn.Module objects of lib/network.py; the Python classes of
+ * densefusion_amd/lib/network.py own one handle each and keep the reference's state_dict keys)
+ *
+ * A handle owns device copies of the parameters in kernel-friendly layouts (channels-last conv
+ * weights, the r/t/c towers stacked, head layer 1 split into its per-point and global-feature parts).
+ * Parameters are handed over one state-dict tensor at a time, in the REFERENCE's layout and under the
+ * REFERENCE's key (e.g. "cnn.model.module.feats.layer3.0.conv1.weight", "feat.conv5.bias",
+ * "conv4_r.weight"), so a checkpoint written by tools/train.py:172-176,211-217 loads unchanged.
+ * Creation/loading may allocate and synchronise; forward calls never do.
+ */
+typedef struct df_net df_net;
+
+df_net *df_posenet_create(int num_points, int num_obj);   /* PoseNet(num_points, num_obj), lib/network.py:70-93 */
+df_net *df_refiner_create(int num_points, int num_obj);   /* PoseRefineNet(...),          lib/network.py:170-185 */
+void df_net_destroy(df_net *net);
+int df_net_num_params(const df_net *net);                  /* 77 tensors for PoseNet, 24 for the refiner */
+int df_net_param_info(const df_net *net, int i, char *key_out, int key_cap, int64_t *shape4, int *ndim);
+/* ptr: `numel` fp32 values in the reference layout (device or host pointer) */
+int df_net_load_param(df_net *net, const char *key, const float *ptr, int64_t numel);
+
+/* Batched PoseNet.forward (lib/network.py:95-132), eval mode (Dropout2d = identity).
+ *   img    [B][3][H][W] fp32 NCHW (normalised crop, tools/eval_ycb.py:175-181)
+ *   cloud  [B][N][3]    fp32        choose [B][N] int64 (row-major pixel index into the H x W crop)
+ *   obj    [B]          int64
+ *   out_r  [B][N][4] (un-normalised quaternion w,x,y,z)   out_t [B][N][3]   out_c [B][N] (sigmoid)
+ *   emb    [B][32][N]  (log-softmax colour features at the chosen pixels; what the refiner consumes)
+ * ws: caller-provided scratch of at least df_posenet_workspace_bytes(net, B, H, W) bytes. */
+size_t df_posenet_workspace_bytes(const df_net *net, int B, int H, int W);
+int df_posenet_forward(df_net *net, int B, int H, int W, const float *img, const float *cloud, const int64_t *choose,
+                       const int64_t *obj, float *out_r, float *out_t, float *out_c, float *emb, void *ws,
+                       size_t ws_bytes, df_stream_t stream);
+
+/* Batched PoseRefineNet.forward (lib/network.py:187-206): x [B][N][3], emb [B][32][N], obj [B]
+ * -> out_r [B][4], out_t [B][3]. */
+size_t df_refiner_workspace_bytes(const df_net *net, int B);
+int df_refiner_forward(df_net *net, int B, const float *x, const float *emb, const int64_t *obj, float *out_r,
+                       float *out_t, void *ws, size_t ws_bytes, df_stream_t stream);
+
+/* The inner loop of tools/eval_ycb.py:192-229 / tools/eval_linemod.py:81-114 for B objects, with no
+ * host round trip: PoseNet -> arg-max-confidence pose -> `iters` x (cloud into the pose frame ->
+ * refiner -> compose).  pose_wo (optional) and pose: [B][7] fp64 = quaternion (w,x,y,z) then
+ * translation, i.e. the rows the reference writes to its result .mat files (eval_ycb.py:203,231). */
+size_t df_estimate_workspace_bytes(const df_net *posenet, const df_net *refiner, int B, int H, int W);
+int df_estimate_poses(df_net *posenet, df_net *refiner, int B, int H, int W, const float *img, const float *cloud,
+                      const int64_t *choose, const int64_t *obj, int iters, double *pose_wo, double *pose, void *ws,
+                      size_t ws_bytes, df_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Building block, exposed for unit parity tests and for callers that want single layers: channels-last
+ * convolution / per-point GEMM on the fp32 matrix cores with the fused epilogue.
+ *   out[b][oy][ox][out_coff + n] = act( sum_{ky,kx,c} in[b][oy*stride - pad + ky*dil][ox*stride - pad + kx*dil][in_coff + c]
+ *                                        * wgt[n][ky][kx][c] + bias[n] + res[b][oy][ox][res_coff + n] )
+ * in rows are in_ld floats wide, out rows out_ld, res rows res_ld; Cin, in_ld, in_coff multiples of 4;
+ * multi-tap kernels need a power-of-two Cin.  act: 0 none, 1 ReLU, 2 PReLU (one slope at *prelu).
+ * bias / res / prelu may be NULL. */
+typedef struct df_conv_desc {
+  const float *in, *wgt, *bias, *res, *prelu;
+  float *out;
+  int32_t B, H, W, Cin, in_ld, in_coff;
+  int32_t OH, OW, Cout, out_ld, out_coff;
+  int32_t res_ld, res_coff;
+  int32_t KH, KW, stride, pad, dil, act;
+} df_conv_desc;
+int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream);
+
+/* Per-launch timing of the GEMM kernel with HIP events on the call's stream (bench.py roofline).
+ * df_net_profile(net, 1) arms it; after the stream has been synchronised df_net_profile_read returns the
+ * summed duration (ms), the algorithmic FLOPs and the number of GEMM launches since arming, and re-arms. */
+int df_net_profile(df_net *net, int enable);
+int df_net_profile_read(df_net *net, double *gemm_ms, double *gemm_flops, int *launches);
+
 #ifdef __cplusplus
 }
 #endif

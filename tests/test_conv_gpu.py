@@ -1,0 +1,82 @@
+"""GPU: the implicit-GEMM fp32-MFMA kernel against a plain PyTorch fp32 CPU reference of the same op."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (B, H, W, Cin, Cout, k, stride, pad, dil): every geometry the network uses + ragged edges
+GEOMS = [
+    (2, 40, 40, 4, 64, 7, 2, 3, 1),       # stem (Cin padded to 4)
+    (2, 10, 10, 64, 64, 3, 1, 1, 1),      # layer1
+    (1, 10, 10, 64, 128, 3, 2, 1, 1),     # layer2.0.conv1 (stride 2)
+    (1, 10, 10, 64, 128, 1, 2, 0, 1),     # layer2.0.downsample
+    (3, 5, 5, 256, 256, 3, 1, 2, 2),      # layer3.1 (dilation 2)
+    (2, 5, 7, 512, 512, 3, 1, 4, 4),      # layer4.1 (dilation 4, non-square)
+    (1, 9, 11, 128, 192, 3, 1, 1, 1),     # Cout not a multiple of the tile, odd sizes
+    (16, 1, 1, 2560, 1024, 1, 1, 0, 1),   # psp bottleneck as GEMM rows
+    (1, 37, 1, 384, 640, 1, 1, 0, 1),     # per-point GEMM with a ragged M
+    (4, 20, 20, 1024, 256, 3, 1, 1, 1),   # up_1: large K = 9216, 128x128 tile path
+    (1, 3, 3, 32, 64, 1, 1, 0, 1),        # tiny
+]
+
+
+def _ref(x_nhwc, w_ohwi, bias, stride, pad, dil):
+    x = x_nhwc.permute(0, 3, 1, 2).contiguous()
+    w = w_ohwi.permute(0, 3, 1, 2).contiguous()
+    return F.conv2d(x, w, bias, stride=stride, padding=pad, dilation=dil).permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_conv_matches_torch_cpu(geom):
+    from densefusion_amd.ops import conv2d_nhwc
+    B, H, W, Cin, Cout, k, s, p, d = geom
+    g = torch.Generator().manual_seed(sum(geom))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = _ref(x, w, b, s, p, d)
+    out = conv2d_nhwc(x.cuda(), w.cuda(), b.cuda(), stride=s, pad=p, dil=d).cpu()
+    assert out.shape == ref.shape
+    tol = 1e-5 * max(1.0, ref.abs().max().item())
+    assert (out - ref).abs().max().item() <= tol
+
+
+def test_conv_epilogue_residual_relu_prelu_and_channel_offsets():
+    from densefusion_amd.ops import conv2d_nhwc
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 6, 6, 96, generator=g)            # use channels 32..95 of a 96-wide row
+    w = torch.randn(64, 3, 3, 64, generator=g) / 24.0
+    b = torch.randn(64, generator=g)
+    res = torch.randn(2, 6, 6, 64, generator=g)
+    ref = _ref(x[..., 32:96].contiguous(), w, b, 1, 1, 1)
+    relu = torch.relu(ref + res)
+    out = torch.full((2, 6, 6, 160), -7.0).cuda()        # write at channel offset 64 of a 160-wide row
+    conv2d_nhwc(x.cuda(), w.cuda(), b.cuda(), pad=1, act=1, res=res.cuda(), out=out, out_coff=64, in_coff=32, cin=64)
+    out = out.cpu()
+    assert (out[..., 64:128] - relu).abs().max().item() < 1e-5 * max(1.0, relu.abs().max().item())
+    assert (out[..., :64] == -7.0).all() and (out[..., 128:] == -7.0).all()      # neighbours untouched
+    slope = torch.tensor([0.25])
+    pre = F.prelu(ref, slope)
+    out2 = conv2d_nhwc(x.cuda(), w.cuda(), b.cuda(), pad=1, act=2, prelu=slope.cuda(), in_coff=32, cin=64).cpu()
+    assert (out2 - pre).abs().max().item() < 1e-5 * max(1.0, pre.abs().max().item())
+
+
+def test_conv_is_exact_on_integers():
+    """fp32 MFMA is an exact fma chain: small-integer data must come out bit-exact, and an asymmetric
+    weight matrix catches a transposed fragment layout."""
+    from densefusion_amd.ops import conv2d_nhwc
+    g = torch.Generator().manual_seed(9)
+    x = torch.randint(-3, 4, (1, 1, 200, 64), generator=g).float()
+    w = torch.randint(-3, 4, (192, 1, 1, 64), generator=g).float()
+    ref = x.reshape(200, 64) @ w.reshape(192, 64).t()
+    out = conv2d_nhwc(x.cuda(), w.cuda()).cpu().reshape(200, 192)
+    assert torch.equal(out, ref)
+
+
+def test_conv_argument_errors():
+    from densefusion_amd.ops import conv2d_nhwc
+    with pytest.raises(RuntimeError):
+        conv2d_nhwc(torch.zeros(1, 4, 4, 6).cuda(), torch.zeros(8, 1, 1, 6).cuda())        # Cin % 4
+    with pytest.raises(RuntimeError):
+        conv2d_nhwc(torch.zeros(1, 4, 4, 12).cuda(), torch.zeros(8, 3, 3, 12).cuda(), pad=1)  # multi-tap non-pow2

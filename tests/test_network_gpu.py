@@ -1,0 +1,134 @@
+"""GPU: PoseNet / PoseRefineNet / the on-device refine loop through the C ABI, against the golden
+vectors of the imported reference (tests/golden) and the CPU oracle on the same seeded inputs.
+
+Tolerances: per-tensor max-abs error <= 2e-4 x tensor scale for raw network outputs (fp32 MFMA vs
+oneDNN/MKL accumulation order through ~25 un-normalised layers); final poses are compared through
+the ADD of the transformed model points, bar 1e-4 m (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from densefusion_amd import synth
+from oracle import dfnet, pose_math
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+CAMS = {"cfg1_linemod_80": synth.LINEMOD_CAM, "cfg2_linemod_120x160": synth.LINEMOD_CAM}
+ADD_TOL = 1e-4
+
+
+def _nets(K, N, wseed):
+    from densefusion_amd.lib.network import PoseNet, PoseRefineNet
+    est, ref = PoseNet(N, K), PoseRefineNet(N, K)
+    est.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.posenet_spec(K), wseed).items()}, strict=True)
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.refiner_spec(K), wseed + 1000).items()}, strict=True)
+    return est.cuda().eval(), ref.cuda().eval()
+
+
+def _case(name):
+    g = np.load(os.path.join(G, name + ".npz"))
+    K, N, H, W, iters, wseed, iseed = [int(v) for v in g["meta"]]
+    o = synth.make_object(iseed, H, W, N, K, cam=CAMS.get(name, synth.YCB_CAM))
+    return g, (K, N, H, W, iters, wseed), o
+
+
+def _close(a, b, rtol=2e-4):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(np.abs(b).max(), 1e-12)
+    err = np.abs(a - b).max()
+    assert err <= rtol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+def _add(p, q, mp):
+    return pose_math.add_metric(pose_math.transform_model(p, mp), pose_math.transform_model(q, mp))
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg1_linemod_80", "cfg2_linemod_120x160", "cfg3_ycb_160", "cfg3_ycb_80x120"])
+def test_posenet_forward_golden(name):
+    g, (K, N, H, W, iters, wseed), o = _case(name)
+    est, _ = _nets(K, N, wseed)
+    T = lambda k: torch.from_numpy(o[k])[None].cuda()
+    r, t, c, emb = est(T("img"), T("cloud"), torch.from_numpy(o["choose"]).cuda(), torch.from_numpy(o["obj"]).cuda())
+    assert r.shape == (1, N, 4) and t.shape == (1, N, 3) and c.shape == (1, N, 1) and emb.shape == (1, 32, N)
+    _close(emb, g["emb"]); _close(r, g["out_rx"]); _close(t, g["out_tx"]); _close(c, g["out_cx"])
+    assert int(c.view(-1).argmax()) == int(g["which_max"][0])
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg2_linemod_120x160", "cfg3_ycb_160", "cfg3_ycb_80x120"])
+def test_estimate_poses_golden(name):
+    """df_estimate_poses == the eval loop of the reference (tools/eval_ycb.py:192-229), ADD <= 1e-4 m."""
+    from densefusion_amd.lib.network import PoseEstimator
+    g, (K, N, H, W, iters, wseed), o = _case(name)
+    est, ref = _nets(K, N, wseed)
+    pe = PoseEstimator(est, ref)
+    T = lambda k: torch.from_numpy(o[k])[None].cuda()
+    wo, pose = pe.estimate(T("img"), T("cloud"), torch.from_numpy(o["choose"]).cuda(), torch.from_numpy(o["obj"]).cuda(), iters)
+    wo, pose = wo.cpu().numpy()[0], pose.cpu().numpy()[0]
+    assert _add(wo, g["pose_wo_refine"], o["model_points"]) < ADD_TOL
+    assert _add(pose, g["poses_refined"][-1], o["model_points"]) < ADD_TOL
+    if name == "cfg3_ycb_160":   # the YCB eval setting (2 iterations, eval_ycb.py:47) from the same golden
+        _, pose2 = pe.estimate(T("img"), T("cloud"), torch.from_numpy(o["choose"]).cuda(), torch.from_numpy(o["obj"]).cuda(), 2)
+        assert _add(pose2.cpu().numpy()[0], g["poses_refined"][1], o["model_points"]) < ADD_TOL
+
+
+def test_refiner_forward_golden_and_api():
+    g, (K, N, H, W, iters, wseed), o = _case("tiny")
+    est, ref = _nets(K, N, wseed)
+    cloud = torch.from_numpy(o["cloud"])[None]
+    my_r, my_t = g["pose_wo_refine"][:4].astype(np.float32), g["pose_wo_refine"][4:].astype(np.float32)
+    R = torch.from_numpy(pose_math.quaternion_matrix(my_r)[:3, :3].astype(np.float32)).view(1, 3, 3)
+    new_cloud = torch.bmm(cloud - torch.from_numpy(my_t).view(1, 1, 3), R)
+    pr, pt = ref(new_cloud.cuda(), torch.from_numpy(g["emb"]).cuda(), torch.from_numpy(o["obj"]).cuda())
+    assert pr.shape == (1, 4) and pt.shape == (1, 3)
+    _close(pr, g["refine0_rx"]); _close(pt, g["refine0_tx"])
+
+
+def test_batched_objects_equal_solo_runs_and_oracle():
+    """Batch extension: B same-size objects in one call == B solo calls (bit-identical), and every
+    object agrees with the CPU oracle (ADD of the selected + refined pose <= 1e-4 m)."""
+    from densefusion_amd.lib.network import PoseEstimator
+    K, N, H, W, B = 21, 1000, 120, 160, 3
+    est, ref = _nets(K, N, 13)
+    pe = PoseEstimator(est, ref)
+    b = synth.make_batch(77, B, H, W, N, K)
+    T = lambda k: torch.from_numpy(b[k]).cuda()
+    wo, pose = pe.estimate(T("img"), T("cloud"), T("choose"), T("obj"), 2)
+    r, t, c, emb = est(T("img"), T("cloud"), T("choose"), T("obj"))
+    sdp = dfnet._to_torch_sd(synth.make_state_dict(synth.posenet_spec(K), 13))
+    sdr = dfnet._to_torch_sd(synth.make_state_dict(synth.refiner_spec(K), 1013))
+    for i in range(B):
+        sl = lambda k: torch.from_numpy(b[k][i:i + 1]).cuda()
+        wo1, pose1 = pe.estimate(sl("img"), sl("cloud"), sl("choose"), sl("obj"), 2)
+        assert torch.equal(wo1[0], wo[i]) and torch.equal(pose1[0], pose[i])
+        r1, t1, c1, e1 = est(sl("img"), sl("cloud"), sl("choose"), sl("obj"))
+        assert torch.equal(r1[0], r[i]) and torch.equal(c1[0], c[i]) and torch.equal(e1[0], emb[i])
+        with torch.no_grad():
+            args = tuple(torch.from_numpy(b[k][i:i + 1]) for k in ("img", "cloud", "choose", "obj"))
+            o_r, o_t, o_c, o_e = dfnet.posenet_forward(sdp, *args)
+            cs = torch.sort(o_c.view(-1))[0]
+            owo, opose = pose_math.estimate_pose(sdp, sdr, *args, 2)
+        _close(emb[i], o_e[0]); _close(r[i], o_r[0]); _close(c[i], o_c[0])
+        if float(cs[-1] - cs[-2]) > 1e-4:       # arg-max is discontinuous: only compare away from ties
+            assert _add(pose[i].cpu().numpy(), opose, b["model_points"][i]) < ADD_TOL
+
+
+def test_state_dict_contract_and_errors():
+    from densefusion_amd.lib.network import PoseNet, PoseRefineNet
+    est, ref = PoseNet(500, 13), PoseRefineNet(500, 13)
+    assert [(k, tuple(v.shape)) for k, v in est.state_dict().items()] == synth.posenet_spec(13)
+    assert [(k, tuple(v.shape)) for k, v in ref.state_dict().items()] == synth.refiner_spec(13)
+    assert sum(p.numel() for p in est.parameters()) == 21440800
+    est.cuda()
+    with pytest.raises(RuntimeError):                                       # train() mode not implemented
+        est(torch.zeros(1, 3, 80, 80).cuda(), torch.zeros(1, 500, 3).cuda(), torch.zeros(1, 1, 500, dtype=torch.long).cuda(),
+            torch.zeros(1, 1, dtype=torch.long).cuda())
+    est.eval()
+    with pytest.raises(RuntimeError):                                       # CPU tensors are refused (no CPU path)
+        est(torch.zeros(1, 3, 80, 80), torch.zeros(1, 500, 3), torch.zeros(1, 1, 500, dtype=torch.long), torch.zeros(1, 1, dtype=torch.long))
+    with pytest.raises(RuntimeError):                                       # wrong point count
+        est(torch.zeros(1, 3, 80, 80).cuda(), torch.zeros(1, 400, 3).cuda(), torch.zeros(1, 1, 400, dtype=torch.long).cuda(),
+            torch.zeros(1, 1, dtype=torch.long).cuda())
