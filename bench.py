@@ -1,0 +1,281 @@
+#!/usr/bin/env python
+"""bench.py -- poses/sec of the DenseFusion hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the whole hot path (PoseNet -> per-pixel pose selection -> 2 refine
+iterations, all on the device) over one batch of synthetic (frame, object) samples already resident
+in HBM: the YCB-Video-shaped stream of SURVEY 8d config 3 -- K=21 objects, N=1000 points, crops cycled
+over seven snapped sizes, `--per-bucket` objects of each size per step (5 objects/frame).  Objects of
+one crop size are evaluated as one batched launch sequence; the step is captured in a hipGraph.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (weak scaling:
+        every rank owns its own batch; no collective on the data path, one tiny all_gather of the
+        [n,7] poses per step)
+
+Prints ONE JSON line (rank 0).  Extra objects in it:
+  roofline     -- the implicit-GEMM fp32-MFMA kernel (igemm_f32_kernel, >90 % of the step): algorithmic
+                  FLOPs / summed launch durations, durations taken with HIP events on the launch stream
+                  in an instrumented re-run of the same steps (events between launches would perturb
+                  the timed region itself)
+  knn          -- the fused 1-NN kernel at the YCB symmetric-loss size (R=500, Q=500 000)
+  cpu_baseline -- the CPU oracle (a port of the reference path) timed on this host, bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from densefusion_amd import _lib, synth  # noqa: E402
+from densefusion_amd.lib.knn import KNearestNeighbor  # noqa: E402
+from densefusion_amd.lib.network import PoseEstimator, PoseNet, PoseRefineNet  # noqa: E402
+
+CROPS = [(80, 80), (120, 120), (120, 160), (160, 160), (160, 200), (200, 240), (240, 320)]   # SURVEY 8d cfg 3
+K_OBJ, N_PTS, ITERS = 21, 1000, 2
+WSEED = 13
+FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA = vector peak
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_gflop_per_pose(H, W):
+    # 0.896 MFLOP x H*W (CNN) + 7.98 MFLOP x N (point MLPs + heads) + iters x 1.481 MFLOP x N
+    return (0.896e6 * H * W + 7.98e6 * N_PTS + ITERS * 1.481e6 * N_PTS) / 1e9
+
+
+def load_nets(device):
+    est, ref = PoseNet(N_PTS, K_OBJ), PoseRefineNet(N_PTS, K_OBJ)
+    est.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.posenet_spec(K_OBJ), WSEED).items()})
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.refiner_spec(K_OBJ), WSEED + 1000).items()})
+    return est.to(device).eval(), ref.to(device).eval()
+
+
+def make_buckets(rank, per_bucket, device):
+    buckets = []
+    for bi, (H, W) in enumerate(CROPS):
+        b = synth.make_batch(3000 + 100 * rank + bi, per_bucket, H, W, N_PTS, K_OBJ)
+        buckets.append(dict(H=H, W=W, host=b,
+                            img=torch.from_numpy(b["img"]).to(device), cloud=torch.from_numpy(b["cloud"]).to(device),
+                            choose=torch.from_numpy(b["choose"]).to(device), obj=torch.from_numpy(b["obj"]).to(device),
+                            out=(torch.empty(per_bucket, 7, dtype=torch.float64, device=device),
+                                 torch.empty(per_bucket, 7, dtype=torch.float64, device=device))))
+    return buckets
+
+
+def run_step(pe, buckets):
+    for b in buckets:
+        pe.estimate(b["img"], b["cloud"], b["choose"], b["obj"], ITERS, out=b["out"])
+
+
+def profile_gemm(pe, buckets, steps):
+    L = _lib.lib()
+    hp, hr = pe.estimator._handle, pe.refiner._handle
+    L.df_net_profile(hp, 1); L.df_net_profile(hr, 1)
+    tot_ms = tot_fl = 0.0
+    tot_n = 0
+    for _ in range(steps):
+        run_step(pe, buckets)
+        torch.cuda.synchronize()
+        for h in (hp, hr):
+            ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+            _lib.check(L.df_net_profile_read(h, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "profile_read")
+            tot_ms += ms.value; tot_fl += fl.value; tot_n += n.value
+    L.df_net_profile(hp, 0); L.df_net_profile(hr, 0)
+    return tot_ms, tot_fl, tot_n
+
+
+def bench_knn():
+    R, Q = 500, 500000
+    knn = KNearestNeighbor(1)
+    ref = (torch.rand(1, 3, R, device="cuda") - 0.5) * 0.2
+    qry = (torch.rand(1, 3, Q, device="cuda") - 0.5) * 0.25
+    for _ in range(3):
+        knn(ref, qry)
+    n = 50
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        knn(ref, qry)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    byts, flops = 12 * (R + Q) + 8 * Q, 9.0 * R * Q
+    gbs, tfl = byts / us / 1e3, flops / us / 1e6
+    return {"kernel": "knn1_dim3_kernel", "R": R, "Q": Q, "us_per_launch": round(us, 2),
+            "algorithmic_bytes": byts, "achieved_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+            "algorithmic_flops": flops, "achieved_TFLOPs": round(tfl, 2), "fp32_valu_frac": round(tfl / FP32_PEAK_TFLOPS, 4),
+            "bound": "fp32-valu (arithmetic intensity 9R/20 = 225 FLOP/B >> ridge ~20)"}
+
+
+def host_threads():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota (a GPU box
+    exposes all host cores in os.cpu_count() but grants a 16-core share per GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:   # noqa: BLE001
+        pass
+    return max(1, min(n, int(os.environ.get("DF_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(buckets, gpu_poses, budget_s=14.0):
+    """The CPU oracle (port of the reference path) on this host: one pose per crop size per round."""
+    from oracle import dfnet, pose_math
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    sdp = dfnet._to_torch_sd(synth.make_state_dict(synth.posenet_spec(K_OBJ), WSEED))
+    sdr = dfnet._to_torch_sd(synth.make_state_dict(synth.refiner_spec(K_OBJ), WSEED + 1000))
+
+    def one(b, i):
+        h = b["host"]
+        args = tuple(torch.from_numpy(h[k][i:i + 1]) for k in ("img", "cloud", "choose", "obj"))
+        with torch.no_grad():
+            return pose_math.estimate_pose(sdp, sdr, *args, ITERS)
+
+    one(buckets[0], 0); one(buckets[3], 0)             # warm-up
+    n, worst_add, checked = 0, 0.0, 0
+    t0 = time.perf_counter()
+    rnd = 0
+    while True:
+        for bi, b in enumerate(buckets):
+            i = rnd % b["img"].shape[0]
+            _, pose = one(b, i)
+            n += 1
+            mp = b["host"]["model_points"][i]
+            add = pose_math.add_metric(pose_math.transform_model(pose, mp), pose_math.transform_model(gpu_poses[bi][i], mp))
+            worst_add = max(worst_add, add); checked += 1
+        rnd += 1
+        if time.perf_counter() - t0 > budget_s or rnd >= 8:
+            break
+    dt = time.perf_counter() - t0
+    return ({"value": round(n / dt, 3), "unit": "poses/s", "cores": threads, "kind": "port",
+             "sample": f"{n} poses = {rnd} round(s) of one pose per crop size {CROPS}, K=21, N=1000, 2 refine iters, "
+                       f"oracle/ (torch CPU fp32) in {dt:.1f} s"},
+            {"max_add_m_vs_oracle": float(f"{worst_add:.3e}"), "objects_checked": checked, "tolerance_m": 1e-4})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--per-bucket", type=int, default=10, help="objects of each crop size per step and GPU")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-knn", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    est, ref = load_nets(device)
+    pe = PoseEstimator(est, ref)
+    buckets = make_buckets(rank, args.per_bucket, device)
+    poses_per_step = args.per_bucket * len(CROPS)
+    gathered = [torch.empty(poses_per_step, 7, dtype=torch.float64, device=device) for _ in range(world)] if world > 1 else None
+
+    def step():
+        run_step(pe, buckets)
+        if world > 1:   # results to every rank: the only communication of the inference path
+            dist.all_gather(gathered, torch.cat([b["out"][1] for b in buckets]))
+
+    run_step(pe, buckets)                      # eager pass: uploads weights, sizes the workspace
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                run_step(pe, buckets)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                run_step(pe, buckets)
+        except Exception as e:                 # noqa: BLE001
+            print(f"[bench] hipGraph capture failed ({e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def timed_step():
+        if graph is not None:
+            graph.replay()
+            if world > 1:
+                dist.all_gather(gathered, torch.cat([b["out"][1] for b in buckets]))
+        else:
+            step()
+
+    for _ in range(args.warmup):
+        timed_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        timed_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        total_poses = poses_per_step * world * args.steps
+        gflop_step = sum(algorithmic_gflop_per_pose(H, W) for H, W in CROPS) * args.per_bucket
+        out = {
+            "metric": "poses/sec (node) YCB-Video 1000 pts + 2 refine iters",
+            "value": round(total_poses / dt, 2), "unit": "poses/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ycb_video_synthetic_stream (BASELINE configs[2] shape at the metric's 2 refine iters: "
+                                   "K=21 objects, N=1000 points, crops cycled over 80x80..240x320, 5 objects/frame)",
+                       "num_obj": K_OBJ, "num_points": N_PTS, "refine_iters": ITERS, "crops": CROPS,
+                       "objects_per_step_per_gpu": poses_per_step, "frames_per_step_per_gpu": poses_per_step / 5,
+                       "hipgraph": graph is not None, "sharding": f"objects round-robin over {world} rank(s), no data-path collective",
+                       "algorithmic_gflop_per_step_per_gpu": round(gflop_step, 1)},
+            "end_to_end_tflops_per_gpu": round(gflop_step * args.steps / dt / 1e3, 2),
+        }
+        ms, fl, n = profile_gemm(pe, buckets, min(args.steps, 5))
+        ach = fl / ms / 1e9 if ms > 0 else 0.0
+        out["roofline"] = {"kernel": "igemm_f32_kernel (implicit-GEMM conv / per-point GEMM, v_mfma_f32_32x32x2_f32)",
+                           "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": n // max(1, min(args.steps, 5)),
+                           "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
+                           "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
+                           "gemm_ms_per_step": round(ms / max(1, min(args.steps, 5)), 3)}
+        if not args.no_knn:
+            out["knn"] = bench_knn()
+        if world == 1 and not args.no_cpu_baseline:
+            gpu_poses = [b["out"][1].cpu().numpy() for b in buckets]
+            out["cpu_baseline"], out["parity"] = cpu_baseline(buckets, gpu_poses)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,7 @@
 // (PoseRefineNet.forward), lib/pspnet.py:64-77, lib/extractors.py:114-124, tools/eval_ycb.py:192-229.
 // Batch extension: the reference evaluates one object per call (b = 0 hard-coded, network.py:123);
 // every entry point here takes B same-sized objects and evaluates them independently.
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -40,6 +41,7 @@ struct Net {
   bool profiling = false;
   std::vector<hipEvent_t> ev;
   std::vector<double> ev_flops;
+  std::vector<std::string> ev_desc;
   size_t ev_used = 0;
 };
 
@@ -276,6 +278,10 @@ struct Ctx {
     if (n.profiling) {
       hipEventRecord(n.ev[n.ev_used + 1], st);
       n.ev_flops.push_back(conv_flops(p));
+      char d[160];
+      snprintf(d, sizeof(d), "M=%ld N=%d K=%d k%dx%d s%d d%d z%d", (long)p.B * p.OH * p.OW, p.Cout, p.KH * p.KW * p.Cin, p.KH,
+               p.KW, p.stride, p.dil, p.zcount);
+      n.ev_desc.push_back(d);
       n.ev_used += 2;
     }
     if (rc != DF_OK) err = rc;
@@ -565,6 +571,7 @@ extern "C" int df_net_profile(df_net *h, int enable) {
   n->profiling = enable != 0;
   n->ev_used = 0;
   n->ev_flops.clear();
+  n->ev_desc.clear();
   return DF_OK;
 }
 
@@ -578,12 +585,15 @@ extern "C" int df_net_profile_read(df_net *h, double *gemm_ms, double *gemm_flop
     if (hipEventElapsedTime(&t, n->ev[i], n->ev[i + 1]) != hipSuccess) return set_error(DF_ERR_LAUNCH, "profile_read: events not complete");
     ms += t;
     fl += n->ev_flops[i / 2];
+    if (getenv("DF_PROFILE_VERBOSE"))
+      fprintf(stderr, "[df-gemm] %s  %.1f us  %.1f TFLOP/s\n", n->ev_desc[i / 2].c_str(), t * 1e3, n->ev_flops[i / 2] / t / 1e9);
   }
   if (gemm_ms) *gemm_ms = ms;
   if (gemm_flops) *gemm_flops = fl;
   if (launches) *launches = (int)(n->ev_used / 2);
   n->ev_used = 0;
   n->ev_flops.clear();
+  n->ev_desc.clear();
   return DF_OK;
 }
 
