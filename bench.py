@@ -35,7 +35,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from densefusion_amd import _lib, synth  # noqa: E402
+from densefusion_amd import _lib, sharding, synth  # noqa: E402
 from densefusion_amd.lib.knn import KNearestNeighbor  # noqa: E402
 from densefusion_amd.lib.network import PoseEstimator, PoseNet, PoseRefineNet  # noqa: E402
 
@@ -58,11 +58,17 @@ def load_nets(device):
     return est.to(device).eval(), ref.to(device).eval()
 
 
-def make_buckets(rank, per_bucket, device):
+def make_buckets(rank, world, per_bucket, device):
+    """Global stream: object i has crop CROPS[i % 7] and seed 3000+i; rank r evaluates its shard_plan part."""
+    total = per_bucket * len(CROPS) * world
+    sizes = [CROPS[i % len(CROPS)] for i in range(total)]
+    plan = sharding.shard_plan(sizes, world, rank)
     buckets = []
-    for bi, (H, W) in enumerate(CROPS):
-        b = synth.make_batch(3000 + 100 * rank + bi, per_bucket, H, W, N_PTS, K_OBJ)
-        buckets.append(dict(H=H, W=W, host=b,
+    for (H, W), idxs in plan.items():
+        assert len(idxs) == per_bucket
+        objs = [synth.make_object(3000 + i, H, W, N_PTS, K_OBJ) for i in idxs]
+        b = {k: np.stack([o[k] for o in objs]) for k in objs[0]}
+        buckets.append(dict(H=H, W=W, host=b, idx=idxs,
                             img=torch.from_numpy(b["img"]).to(device), cloud=torch.from_numpy(b["cloud"]).to(device),
                             choose=torch.from_numpy(b["choose"]).to(device), obj=torch.from_numpy(b["obj"]).to(device),
                             out=(torch.empty(per_bucket, 7, dtype=torch.float64, device=device),
@@ -189,7 +195,7 @@ def main():
 
     est, ref = load_nets(device)
     pe = PoseEstimator(est, ref)
-    buckets = make_buckets(rank, args.per_bucket, device)
+    buckets = make_buckets(rank, world, args.per_bucket, device)
     poses_per_step = args.per_bucket * len(CROPS)
     gathered = [torch.empty(poses_per_step, 7, dtype=torch.float64, device=device) for _ in range(world)] if world > 1 else None
 
