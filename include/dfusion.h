@@ -99,6 +99,29 @@ int df_estimate_poses(df_net *posenet, df_net *refiner, int B, int H, int W, con
                       size_t ws_bytes, df_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * ADD / ADD-S loss and metric, forward (replace lib/loss.py:13-70, lib/loss_refiner.py:12-62 and the
+ * metric of tools/eval_linemod.py:118-130).  One object per call, like the reference (bs = 1).
+ * `symmetric` != 0 selects the nearest-neighbour (ADD-S) branch -- what `idx[0].item() in sym_list`
+ * (and `not refine` for the PoseNet loss) decides in the reference; the transform, the 1-NN and the
+ * distance reduction are fused, nothing of size N*M is written to memory.
+ *
+ * df_loss_forward:  pred_r [N][4], pred_t [N][3], pred_c [N], target [M][3], model_points [M][3],
+ *   points [N][3], w  ->  loss_out[1] = mean_n(dis_n c_n - w log c_n), dis_out[1] = dis at arg-max c,
+ *   new_points [N][3], new_target [M][3] (re-centred by the arg-max pose); dis_scratch: N floats.
+ * df_loss_refine_forward: pred_r [4], pred_t [3], points [N][3] -> dis_out[1], new_points, new_target.
+ * df_add_metric: B objects; pose [B][7] fp64 (q wxyz, t), model_points/target [B][M][3] fp32,
+ *   symmetric [B] int32 or NULL -> dis_out [B] fp64 (ADD, or ADD-S pred->nearest target). */
+int df_loss_forward(const float *pred_r, const float *pred_t, const float *pred_c, const float *target,
+                    const float *model_points, const float *points, int N, int M, float w, int symmetric,
+                    float *loss_out, float *dis_out, float *new_points, float *new_target, float *dis_scratch,
+                    df_stream_t stream);
+int df_loss_refine_forward(const float *pred_r, const float *pred_t, const float *target, const float *model_points,
+                           const float *points, int N, int M, int symmetric, float *dis_out, float *new_points,
+                           float *new_target, df_stream_t stream);
+int df_add_metric(const double *pose, const float *model_points, const float *target, const int *symmetric, int B,
+                  int M, double *dis_out, df_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Building block, exposed for unit parity tests and for callers that want single layers: channels-last
  * convolution / per-point GEMM on the fp32 matrix cores with the fused epilogue.
  *   out[b][oy][ox][out_coff + n] = act( sum_{ky,kx,c} in[b][oy*stride - pad + ky*dil][ox*stride - pad + kx*dil][in_coff + c]

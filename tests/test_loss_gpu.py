@@ -1,0 +1,95 @@
+"""GPU: Loss / Loss_refine / ADD(-S) metric through the C ABI against the reference goldens
+(non-symmetric branch, run by the imported reference) and the CPU oracle (symmetric branch)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from densefusion_amd import synth
+from oracle import loss_ref, pose_math
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _close(a, b, rtol=2e-5):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if torch.is_tensor(b) else b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.abs(a - b).max() <= rtol * max(np.abs(b).max(), 1e-12), (np.abs(a - b).max(), np.abs(b).max())
+
+
+def test_loss_and_loss_refine_golden_nonsymmetric():
+    from densefusion_amd.lib.loss import Loss
+    from densefusion_amd.lib.loss_refiner import Loss_refine
+    g = np.load(os.path.join(G, "loss_nonsym.npz"))
+    T = lambda k: torch.from_numpy(g[k]).cuda()
+    M = g["target"].shape[1]
+    idx = torch.tensor([[3]]).cuda()
+    loss, dis, npts, ntgt = Loss(M, [7, 8])(T("pred_r"), T("pred_t"), T("pred_c"), T("target"), T("model_points"), idx,
+                                            T("points"), 0.015, False)
+    assert loss.dim() == 0 and dis.dim() == 0 and npts.shape == (1, g["points"].shape[1], 3) and ntgt.shape == (1, M, 3)
+    _close(loss, g["loss"]); _close(dis, g["dis"]); _close(npts, g["new_points"]); _close(ntgt, g["new_target"])
+    d2, np2, nt2 = Loss_refine(M, [7, 8])(T("r_pred_r"), T("r_pred_t"), ntgt, T("model_points"), idx, npts)
+    assert d2.shape == (1,)
+    _close(d2, g["r_dis"]); _close(np2, g["r_new_points"]); _close(nt2, g["r_new_target"])
+
+
+@pytest.mark.parametrize("N,M,refine", [(96, 80, False), (500, 500, False), (64, 2600, False), (200, 500, True)])
+def test_loss_symmetric_vs_oracle(N, M, refine):
+    """Symmetric objects: fused transform + 1-NN + reduction == oracle (materialise, knn_ref.c, gather)."""
+    from densefusion_amd.lib.loss import Loss
+    from densefusion_amd.lib.loss_refiner import Loss_refine
+    rng = np.random.Generator(np.random.PCG64(N * 3 + M))
+    o = synth.make_object(9000 + N, 80, 80, N, 13, num_points_mesh=M)
+    q = rng.standard_normal((1, N, 4)).astype(np.float32)
+    pt = (rng.standard_normal((1, N, 3)) * 0.03).astype(np.float32)
+    pc = rng.uniform(0.05, 0.95, (1, N, 1)).astype(np.float32)
+    tgt, mp, pts = o["target"][None], o["model_points"][None], o["cloud"][None]
+    idx = torch.tensor([[7]])
+    C = lambda a: torch.from_numpy(a)
+    want = loss_ref.loss_calculation(C(q), C(pt), C(pc), C(tgt), C(mp), idx, C(pts), 0.015, refine, M, [7, 8])
+    got = Loss(M, [7, 8])(C(q).cuda(), C(pt).cuda(), C(pc).cuda(), C(tgt).cuda(), C(mp).cuda(), idx.cuda(), C(pts).cuda(), 0.015, refine)
+    for a, b in zip(got, want):
+        _close(a, b, 5e-5)
+    q1 = rng.standard_normal((1, 4)).astype(np.float32)
+    t1 = (rng.standard_normal((1, 3)) * 0.02).astype(np.float32)
+    wantr = loss_ref.loss_refine_calculation(C(q1), C(t1), want[3], C(mp), idx, want[2], M, [7, 8])
+    gotr = Loss_refine(M, [7, 8])(C(q1).cuda(), C(t1).cuda(), got[3], C(mp).cuda(), idx.cuda(), got[2])
+    for a, b in zip(gotr, wantr):
+        _close(a, b, 5e-5)
+
+
+def test_add_metric_vs_oracle_and_ply_fixture():
+    from densefusion_amd.lib.metric import add_metric
+    rng = np.random.Generator(np.random.PCG64(4))
+    B, M = 5, 500
+    objs = [synth.make_object(700 + i, 80, 80, 64, 13, num_points_mesh=M) for i in range(B)]
+    mp = np.stack([o["model_points"] for o in objs]); tg = np.stack([o["target"] for o in objs])
+    pose = np.zeros((B, 7))
+    for i in range(B):
+        pose[i, :4] = synth.random_unit_quaternion(rng)
+        pose[i, 4:] = objs[i]["cloud"].mean(0) + rng.standard_normal(3) * 0.01
+    sym = np.array([0, 1, 0, 1, 1], dtype=np.int32)
+    got = add_metric(torch.from_numpy(pose).cuda(), torch.from_numpy(mp).cuda(), torch.from_numpy(tg).cuda(), sym).cpu().numpy()
+    for i in range(B):
+        pred = pose_math.transform_model(pose[i], mp[i])
+        want = pose_math.adds_metric(pred, tg[i]) if sym[i] else pose_math.add_metric(pred, tg[i])
+        assert abs(got[i] - want) <= 2e-6 * max(1.0, want), (i, got[i], want)
+    # the two clouds the reference ships: identity pose on `pred` as the model
+    g = np.load(os.path.join(G, "ply_clouds.npz"))
+    ident = torch.tensor([[1.0, 0, 0, 0, 0, 0, 0]], dtype=torch.float64).cuda()
+    P, Tt = torch.from_numpy(g["pred"].astype(np.float32))[None].cuda(), torch.from_numpy(g["target"].astype(np.float32))[None].cuda()
+    assert abs(add_metric(ident, P, Tt)[0].item() - 0.0168566) < 2e-6
+    assert abs(add_metric(ident, P, Tt, [1])[0].item() - 0.0092865) < 2e-6
+    assert abs(add_metric(ident, Tt, P, [1])[0].item() - 0.0095001) < 2e-6
+
+
+def test_loss_argument_errors():
+    from densefusion_amd.lib.loss import Loss
+    z = lambda *s: torch.zeros(*s).cuda()
+    with pytest.raises(RuntimeError):
+        Loss(500, [])(z(1, 10, 4), z(1, 10, 3), z(1, 10, 1), z(1, 400, 3), z(1, 500, 3), torch.tensor([[0]]).cuda(), z(1, 10, 3), 0.015, False)
+    with pytest.raises(RuntimeError):
+        Loss(500, [])(torch.zeros(1, 10, 4), z(1, 10, 3), z(1, 10, 1), z(1, 500, 3), z(1, 500, 3), torch.tensor([[0]]), z(1, 10, 3), 0.015, False)
