@@ -157,6 +157,17 @@ __global__ void pack_oihw_kernel(const float *__restrict__ src, float *__restric
   }
 }
 
+// psp fold (load time): wc[s][m][i] = sum_o wb[m][512 s + o] * ws[s][o][i], accumulated in fp64 and
+// rounded once, so the folded weights carry no more error than a single fp32 rounding
+__global__ void psp_fold_kernel(const float *__restrict__ wb, const float *__restrict__ ws, float *__restrict__ wc, int s) {
+  const int i = blockIdx.x * 256 + threadIdx.x;          // 0..511
+  const int m = blockIdx.y;
+  if (i >= 512) return;
+  double acc = 0.0;
+  for (int o = 0; o < 512; ++o) acc += (double)wb[(size_t)m * 2560 + s * 512 + o] * (double)ws[(size_t)o * 512 + i];
+  wc[((size_t)s * 1024 + m) * 512 + i] = (float)acc;
+}
+
 static bool ends_with(const std::string &s, const char *suf) {
   const size_t l = strlen(suf);
   return s.size() >= l && s.compare(s.size() - l, l, suf) == 0;
@@ -226,6 +237,22 @@ static int load_param(Net &n, const std::string &key, const float *src, int64_t 
   }
   if (e != hipSuccess) return set_error(DF_ERR_LAUNCH, "load_param(%s): %s", key.c_str(), hipGetErrorString(e));
   n.loaded[it->second] = 1;
+  if (n.kind == 0 && key.find(".psp.") != std::string::npos && !ends_with(key, ".bias")) {
+    // (re)build the folded PSP weights once the bottleneck and all four stage weights are present
+    const std::string P = CNN;
+    bool all = n.loaded[n.index[P + "psp.bottleneck.weight"]];
+    for (int st = 0; st < 4; ++st) all = all && n.loaded[n.index[P + "psp.stages." + std::to_string(st) + ".1.weight"]];
+    if (all) {
+      float *wc = dev_alloc(n, "psp.fold.w", (size_t)4 * 1024 * 512), *wf = dev_alloc(n, "psp.fold.wfeat", (size_t)1024 * 512);
+      if (!wc || !wf) return set_error(DF_ERR_LAUNCH, "psp fold: hipMalloc failed");
+      const float *wb = n.buf[P + "psp.bottleneck.weight"];
+      hipMemcpy2D(wf, 512 * sizeof(float), wb + 2048, 2560 * sizeof(float), 512 * sizeof(float), 1024, hipMemcpyDeviceToDevice);
+      for (int st = 0; st < 4; ++st)
+        hipLaunchKernelGGL(psp_fold_kernel, dim3(2, 1024, 1), dim3(256), 0, 0, wb, n.buf[P + "psp.stages." + std::to_string(st) + ".1.weight"], wc, st);
+      hipDeviceSynchronize();
+      if (check_launch("psp fold") != DF_OK) return DF_ERR_LAUNCH;
+    }
+  }
   return DF_OK;
 }
 
@@ -332,7 +359,6 @@ static float *cnn_forward(Ctx &c, int B, int H, int W, const float *img, int &ou
 
   int h = H2, w = W2, cin = 64, x_ld = 64;
   const int planes_of[4] = {64, 128, 256, 512}, stride_of[4] = {1, 2, 1, 1}, dil_of[4] = {1, 1, 2, 4};
-  float *concat = nullptr;
   for (int li = 1; li <= 4; ++li) {
     const int planes = planes_of[li - 1], s = stride_of[li - 1], d = dil_of[li - 1];
     const std::string base = P + "feats.layer" + std::to_string(li) + ".";
@@ -358,13 +384,8 @@ static float *cnn_forward(Ctx &c, int B, int H, int W, const float *img, int &ou
     float *t1 = c.f((size_t)B * oh * ow * planes);
     c.conv(conv2d(o0, B, oh, ow, planes, planes, c.w(base + "1.conv1.weight"), nullptr, t1, oh, ow, planes, planes, 0, 3, 1, d, d, ACT_RELU));
     float *o1;
-    int o1_ld = planes, o1_coff = 0;
-    if (li == 4) {   // feats go straight into the last 512 channels of the PSP concat buffer (pspnet.py:22)
-      concat = c.f((size_t)B * oh * ow * 2560);
-      o1 = concat; o1_ld = 2560; o1_coff = 2048;
-    } else {
-      o1 = c.f((size_t)B * oh * ow * planes);
-    }
+    const int o1_ld = planes, o1_coff = 0;
+    o1 = c.f((size_t)B * oh * ow * planes);
     {
       ConvParams p = conv2d(t1, B, oh, ow, planes, planes, c.w(base + "1.conv2.weight"), nullptr, o1, oh, ow, planes, o1_ld, o1_coff, 3, 1, d, d, ACT_RELU);
       p.res = o0; p.res_ld = planes;
@@ -372,16 +393,26 @@ static float *cnn_forward(Ctx &c, int B, int H, int W, const float *img, int &ou
     }
     x = o1; x_ld = o1_ld; h = oh; w = ow; cin = planes;
   }
-  // PSP module (lib/pspnet.py:20-24)
-  float *pooled = c.f((size_t)50 * B * 512), *stg = c.f((size_t)50 * B * 512);
-  if (c.live()) launch_psp_pool(concat, 2560, 2048, pooled, B, h, w, 512, c.st);
-  const int soff[4] = {0, 1, 5, 14}, ssz[4] = {1, 4, 9, 36};
-  for (int s = 0; s < 4; ++s)
-    c.conv(point_gemm(pooled ? pooled + (size_t)soff[s] * B * 512 : nullptr, 512, 0, 512, c.w(P + "psp.stages." + std::to_string(s) + ".1.weight"),
-                      nullptr, stg ? stg + (size_t)soff[s] * B * 512 : nullptr, 512, 0, 512, B * ssz[s], ACT_NONE));
-  if (c.live()) launch_psp_upsample_concat(stg, concat, 2560, B, h, w, 512, c.st);
+  // PSP module (lib/pspnet.py:20-24) with the bottleneck folded through the pyramid:
+  //   bottleneck(cat(up(W_s pool_s(f)), f)) = W_b[:,2048:] f + sum_s up((W_b[:,512s:512s+512] W_s) pool_s(f)) + b
+  // (1x1 convs and bilinear resampling are linear and commute), so the 2560-channel concat is never built,
+  // the big GEMM shrinks from K=2560 to K=512 and the four stage convs become one grouped launch on
+  // 50 pooled rows per object with weights combined once at load time (psp_fold).
+  float *pooled = c.f((size_t)4 * B * 36 * 512), *zst = c.f((size_t)4 * B * 36 * 1024);
+  if (c.live()) launch_psp_pool(x, 512, 0, pooled, B, h, w, 512, c.st);
+  {
+    ConvParams p = point_gemm(pooled, 512, 0, 512, c.w("psp.fold.w"), nullptr, zst, 1024, 0, 1024, B * 36, ACT_NONE);
+    p.zcount = 4; p.z_in_coff = (long)B * 36 * 512; p.z_wgt = 1024 * 512; p.z_out_coff = (long)B * 36 * 1024;
+    c.conv(p);
+  }
+  float *prior = c.f((size_t)B * h * w * 1024);
+  if (c.live()) launch_psp_prior_sum(zst, prior, B, h, w, 1024, c.st);
   float *psp = c.f((size_t)B * h * w * 1024);
-  c.conv(point_gemm(concat, 2560, 0, 2560, c.w(P + "psp.bottleneck.weight"), c.w(P + "psp.bottleneck.bias"), psp, 1024, 0, 1024, B * h * w, ACT_RELU));
+  {
+    ConvParams p = point_gemm(x, 512, 0, 512, c.w("psp.fold.wfeat"), c.w(P + "psp.bottleneck.bias"), psp, 1024, 0, 1024, B * h * w, ACT_RELU);
+    p.res = prior; p.res_ld = 1024;
+    c.conv(p);
+  }
   // three x2 upsample + 3x3 conv + PReLU stages (lib/pspnet.py:27-37,69-75; dropout = identity in eval)
   float *cur = psp;
   const char *ups[3] = {"up_1", "up_2", "up_3"};

@@ -18,6 +18,8 @@
 // Epilogue fused in registers: bias (shared or per row group), residual add, ReLU / PReLU, store at a
 // channel offset of a wider row (writes straight into concat buffers), and an optional per-wave
 // column sum of the activated tile (the AvgPool1d over points, lib/network.py:65).
+#include <cstdlib>
+
 #include "igemm.h"
 
 namespace df {
@@ -195,15 +197,257 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const ConvParams p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v2: the same tiling, software-pipelined so the matrix pipe never waits for the loader.
+//   * every global access is a bounds-checked buffer load (out-of-range -> 0, no branches), so the
+//     loop body is one basic block and address arithmetic, loads and LDS traffic sit between MFMAs;
+//   * 3-stage pipeline: tile kt is multiplied from LDS while tile kt+1 moves registers -> LDS and
+//     tile kt+2 is in flight from HBM/L2; one barrier per tile, placed BEFORE the last quarter of
+//     the tile's MFMAs so the next tile's first fragment reads hide under them;
+//   * epilogue through LDS: each wave transposes its accumulators so that global stores / residual
+//     loads are 16-byte vectors covering whole 128/256-byte row segments.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;
+  constexpr int TILE = (BM + BN) * LDK;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int M = p.B * p.OH * p.OW;
+  const int K = p.KH * p.KW * p.Cin;
+  const int tiles_n = (p.Cout + BN - 1) / BN;
+  int wgid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int n_tile = wgid % tiles_n, m_tile = wgid / tiles_n;
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+  const int z = blockIdx.z;
+  const int out_coff = p.out_coff + (int)(z * p.z_out_coff);
+
+  // buffer descriptors (wave-uniform): reads past num_records return 0
+  const unsigned in_bytes = (unsigned)(((size_t)p.B * p.H * p.W * p.in_ld + (size_t)(p.zcount - 1) * p.z_in_coff) * sizeof(float));
+  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, in_bytes, 0x00020000);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wgt + (size_t)z * p.z_wgt), 0,
+                                                      (unsigned)((size_t)p.Cout * K * sizeof(float)), 0x00020000);
+  const int in_c0 = p.in_coff + (int)(z * p.z_in_coff);
+
+  const int vec = tid & 7, lrow = tid >> 3;
+  int a_iy0[A_ROWS], a_ix0[A_ROWS], a_off[A_ROWS];   // a_off: element offset of (b, iy0, ix0, first channel)
+#pragma unroll
+  for (int i = 0; i < A_ROWS; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    if (m < M) {
+      const int ohw = p.OH * p.OW;
+      const int b = m / ohw, rem = m - b * ohw;
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      a_iy0[i] = oy * p.stride - p.pad;
+      a_ix0[i] = ox * p.stride - p.pad;
+      a_off[i] = ((b * p.H + a_iy0[i]) * p.W + a_ix0[i]) * p.in_ld + in_c0;
+    } else {
+      a_iy0[i] = -(1 << 28);
+      a_ix0[i] = 0;
+      a_off[i] = 0;
+    }
+  }
+  int b_off[B_ROWS];
+#pragma unroll
+  for (int i = 0; i < B_ROWS; ++i) {
+    const int n = n0 + lrow + 32 * i;
+    b_off[i] = n < p.Cout ? n * K : -1;
+  }
+  const bool one_tap = (p.KH * p.KW == 1);
+  const int cin_shift = 31 - __builtin_clz(p.Cin);
+  const int nkt = (K + BK - 1) / BK;
+
+  // branch-free k -> (tap, channel) decode: single-tap layers use shift 31 / mask ~0 (tap = 0, c = k)
+  const int k_shift = one_tap ? 31 : cin_shift;
+  const int c_mask = one_tap ? 0x7fffffff : p.Cin - 1;
+  const int kw_magic = (65536 + p.KW - 1) / p.KW;     // tap / KW == (tap * kw_magic) >> 16 for tap < 64
+
+  u32x4 ra[A_ROWS], rb[B_ROWS];
+  auto issue_loads = [&](int kt) {
+    const int k = kt * BK + vec * 4;
+    const int kok = k < K;
+    const int tap = k >> k_shift;
+    const int c = k & c_mask;
+    const int ky = (tap * kw_magic) >> 16, kx = tap - ky * p.KW;
+    const int dy = ky * p.dil, dx = kx * p.dil;
+    const int doff = (dy * p.W + dx) * p.in_ld + c;
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+      const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+      // bitwise (not short-circuit) so no control flow is generated: the loop body stays one basic block
+      const int ok = kok & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W);
+      unsigned off = ok ? (unsigned)(a_off[i] + doff) * 4u : 0xffffffffu;
+      asm("" : "+v"(off));      // opaque: keeps hipcc from turning the select into two branchy loads
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) {
+      const int ok = kok & (int)(b_off[i] >= 0);
+      unsigned off = ok ? (unsigned)(b_off[i] + k) * 4u : 0xffffffffu;
+      asm("" : "+v"(off));
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0);
+    }
+  };
+  auto write_lds = [&](int buf) {
+    float *sA = smem + buf * TILE, *sB = sA + BM * LDK;
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) *reinterpret_cast<u32x4 *>(sA + (lrow + 32 * i) * LDK + vec * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<u32x4 *>(sB + (lrow + 32 * i) * LDK + vec * 4) = rb[i];
+  };
+
+  const int li = lane & 31, lh = lane >> 5;
+  const int fa = (wm * WM + li) * LDK + lh * 4;                  // this lane's A-fragment base (floats)
+  const int fb = BM * LDK + (wn * WN + li) * LDK + lh * 4;
+  // fragments of two 8-wide k groups: [half][tile]
+  f32x4 a0[2][TM], b0[2][TN], a1[2][TM], b1[2][TN];
+  auto read_frags = [&](int buf, int gpair, f32x4 (&a)[2][TM], f32x4 (&b)[2][TN]) {
+    const float *base = smem + buf * TILE;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[h][i] = *reinterpret_cast<const f32x4 *>(base + fa + i * 32 * LDK + (gpair * 2 + h) * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[h][j] = *reinterpret_cast<const f32x4 *>(base + fb + j * 32 * LDK + (gpair * 2 + h) * 8);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  auto mfma_group = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+  };
+
+  // prologue: tile 0 -> LDS, tile 1 -> registers
+  issue_loads(0);
+  write_lds(0);
+  issue_loads(1);
+  __syncthreads();
+  read_frags(0, 0, a0, b0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    mfma_group(a0[0], b0[0]);
+    mfma_group(a0[1], b0[1]);
+    read_frags(buf, 1, a1, b1);
+    // Keep the register -> LDS hand-over of tile kt+1 and the issue of tile kt+2 in the third quarter:
+    // the loads then have a full tile of MFMA time (~4k cycles) to land before their ds_write.
+    __builtin_amdgcn_sched_barrier(0);
+    write_lds(buf ^ 1);               // tile kt+1 (zeros past the end): registers -> the idle buffer
+    issue_loads(kt + 2);              // tile kt+2 starts its trip; consumed one full tile later
+    mfma_group(a1[0], b1[0]);
+    __syncthreads();                  // everyone has read tile kt out of `buf`; tile kt+1 is complete in buf^1
+    read_frags(buf ^ 1, 0, a0, b0);   // lands while the last quarter of tile kt multiplies
+    __builtin_amdgcn_sched_barrier(0);  // hipcc would otherwise hoist these MFMAs above the barrier
+    mfma_group(a1[1], b1[1]);
+  }
+  __syncthreads();                    // the speculative fragment reads above are done before smem is reused
+
+  // ---- epilogue: accumulators -> LDS (per-wave region) -> 16-byte row segments ----
+  constexpr int EP_LD = WN + 4;
+  float *ep = smem + wave * (WM * EP_LD);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ep[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * EP_LD + j * 32 + li] = acc[i][j][e];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  const float slope = (p.act == ACT_PRELU) ? p.prelu[0] : 0.f;
+  const int grp = (p.rows_per_group > 0) ? m0 / p.rows_per_group : 0;
+  const float *bias = p.bias ? p.bias + z * p.z_bias + (p.bias_group_ld > 0 ? (size_t)grp * p.bias_group_ld : 0) : nullptr;
+  constexpr int LPR = WN / 4;            // lanes per row
+  constexpr int RPP = 64 / LPR;          // rows per pass
+  const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+  const int n = n0 + wn * WN + c4;
+  const bool nok = n < p.Cout;           // Cout % 4 == 0 (host-checked): a vector is all-in or all-out
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias && nok) bv = *reinterpret_cast<const f32x4 *>(bias + n);
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int ps = 0; ps < WM / RPP; ++ps) {
+    const int row = ps * RPP + r0;
+    const int m = m0 + wm * WM + row;
+    const bool ok = nok && m < M;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(ep + row * EP_LD + c4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += bv[e];
+    if (p.res && ok) {
+      const f32x4 rv = *reinterpret_cast<const f32x4 *>(p.res + (size_t)m * p.res_ld + p.res_coff + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += rv[e];
+    }
+    if (p.act == ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    } else if (p.act == ACT_PRELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+    }
+    if (ok && p.out) *reinterpret_cast<f32x4 *>(p.out + (size_t)m * p.out_ld + out_coff + n) = v;
+    if (p.colsum) {
+      const bool real = ok && (p.rows_per_group <= 0 || (m % p.rows_per_group) < p.rows_valid);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) csum[e] += real ? v[e] : 0.f;
+    }
+  }
+  if (p.colsum) {
+    // lanes with equal (lane % LPR) hold different rows of the same 4 columns: fold them (fixed order)
+#pragma unroll
+    for (int d = 32; d >= LPR; d >>= 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) csum[e] += __shfl_xor(csum[e], d);
+    if (lane < LPR && nok)
+      *reinterpret_cast<f32x4 *>(p.colsum + ((size_t)z * (gridDim.x / tiles_n) * WAVES_M + (size_t)m_tile * WAVES_M + wm) * p.Cout + n) = csum;
+  }
+}
+
 struct TileCfg { int bm, bn, wmv; };
 
 TileCfg pick_cfg(const ConvParams &p) {
   const long M = (long)p.B * p.OH * p.OW;
-  // 128x128 when it still fills the chip (>= ~1 tile per CU) or when rows are grouped (colsum / grouped
-  // bias need BM | rows_per_group); 64x64 for narrow or small problems.
-  const long t128 = ((M + 127) / 128) * ((p.Cout + 127) / 128) * p.zcount;
-  if (p.Cout % 128 == 0 && (t128 >= 192 || p.rows_per_group > 0)) return {128, 128, 2};
+  // Row-grouped launches (fused mean / per-object bias) need BM | rows_per_group: always 128x128.
   if (p.rows_per_group > 0) return {128, 128, 2};
+  // Otherwise pick the tile that minimises  ceil(tiles / 256 CUs) * tile_area / efficiency : the chip
+  // finishes when its most loaded CU does, so a 128x128 grid of e.g. 800 tiles (4 rounds for 3.1 rounds
+  // of work) loses to the same problem cut into 3200 64x64 tiles (13 rounds for 12.5).
+  auto cost = [&](int bm, int bn, double eff) {
+    const long tiles = ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * p.zcount;
+    const long rounds = (tiles + 255) / 256;
+    return (double)rounds * bm * bn / eff;
+  };
+  const double c128 = cost(128, 128, 1.0), c64 = cost(64, 64, 0.96);
+  if (p.Cout >= 128 && c128 <= c64) return {128, 128, 2};
   return {64, 64, 2};
 }
 
@@ -241,10 +485,28 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * LDK * (int)sizeof(float));
     attr_done = true;
   }
-  if (c.bm == 128)
+  const bool force_v1 = getenv("DF_IGEMM_V1") != nullptr;   // dev switch: A/B against the un-pipelined kernel
+  const size_t in_bytes = ((size_t)p.B * p.H * p.W * p.in_ld + (size_t)(p.zcount - 1) * p.z_in_coff) * sizeof(float);
+  const size_t w_bytes = (size_t)p.Cout * p.KH * p.KW * p.Cin * sizeof(float);
+  const bool v2 = !force_v1 && in_bytes < (1ull << 32) && w_bytes < (1ull << 32) && p.Cout % 4 == 0 && p.out_ld % 4 == 0 &&
+                  p.out_coff % 4 == 0 && p.z_out_coff % 4 == 0 && (!p.res || (p.res_ld % 4 == 0 && p.res_coff % 4 == 0)) &&
+                  (!p.bias || (p.bias_group_ld % 4 == 0 && p.z_bias % 4 == 0));
+  if (v2) {
+    static bool attr2 = false;
+    if (!attr2) {
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_f32_v2_kernel<128, 128, 2, 2>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * LDK * (int)sizeof(float));
+      attr2 = true;
+    }
+    if (c.bm == 128)
+      hipLaunchKernelGGL((igemm_f32_v2_kernel<128, 128, 2, 2>), grid, dim3(256), lds, st, p);
+    else
+      hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2>), grid, dim3(256), lds, st, p);
+  } else if (c.bm == 128) {
     hipLaunchKernelGGL((igemm_f32_kernel<128, 128, 2, 2>), grid, dim3(256), lds, st, p);
-  else
+  } else {
     hipLaunchKernelGGL((igemm_f32_kernel<64, 64, 2, 2>), grid, dim3(256), lds, st, p);
+  }
   return check_launch("igemm");
 }
 

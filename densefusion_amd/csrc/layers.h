@@ -11,11 +11,12 @@ void launch_maxpool3s2(const float *in, float *out, int B, int H, int W, int C, 
 // nn.Upsample(scale_factor=2, bilinear, align_corners=True) on NHWC (lib/pspnet.py:31)
 void launch_upsample2x_ac(const float *in, float *out, int B, int H, int W, int C, hipStream_t st);
 // AdaptiveAvgPool2d(s) for s in {1,2,3,6} (lib/pspnet.py:15-17); in = NHWC rows of width in_ld at channel
-// offset in_coff; out = 4 stage blocks [B*s*s][C] laid back to back (stage offsets 0, B, 5B, 14B rows)
+// offset in_coff; out = 4 stage blocks of B*36 rows each ([4][B*36][C]; stage s fills its first B*s*s rows)
 void launch_psp_pool(const float *in, int in_ld, int in_coff, float *out, int B, int H, int W, int C, hipStream_t st);
-// F.upsample(size=(H,W), bilinear) with align_corners=False of the 4 stage maps into the concat buffer
-// (lib/pspnet.py:22): out[b][y][x][stage*C + c], row width out_ld
-void launch_psp_upsample_concat(const float *stages, float *out, int out_ld, int B, int H, int W, int C, hipStream_t st);
+// sum over the 4 stages of F.upsample(size=(H,W), bilinear, align_corners=False) (lib/pspnet.py:22) of the
+// stage maps z ([4][B*36][C], already multiplied by the folded stage x bottleneck weights) -> out [B][H][W][C]
+void launch_psp_prior_sum(const float *z, float *out, int B, int H, int W, int C, hipStream_t st);
+void launch_transpose2d(const float *in, float *out, int R, int C, hipStream_t st);
 // final 1x1 conv 64->32 + LogSoftmax over channels (lib/pspnet.py:53-56) evaluated ONLY at the N chosen
 // pixels (lib/network.py:98-102).  feat [B][H*W][64]; choose [B][N] int64; emb [B][32][N] (reference
 // layout, returned to the caller) and emb_pm [B][Npad][32] (point-major, for the MLPs)

@@ -111,11 +111,12 @@ __device__ inline void psp_bin(int bin, int &s, int &local) {
   else if (bin < 14) { s = 3; local = bin - 5; }
   else { s = 6; local = bin - 14; }
 }
-__device__ __host__ inline int psp_stage_off(int stage) { return stage == 0 ? 0 : stage == 1 ? 1 : stage == 2 ? 5 : 14; }
 
-// grid (50, B); thread = one float4 of channels
-__global__ __launch_bounds__(128) void psp_pool_kernel(const float *__restrict__ in, int in_ld, int in_coff,
+// grid (50, B); thread = one float4 of channels.  Output: 4 stage blocks of B*36 rows each
+// ([4][B*36][C], stage s uses its first B*s*s rows) so the 4 stage GEMMs run as one grouped launch.
+__global__ __launch_bounds__(512) void psp_pool_kernel(const float *__restrict__ in, int in_ld, int in_coff,
                                                        float *__restrict__ out, int B, int H, int W, int C) {
+  __shared__ f32x4 s_part[4][128];
   int s, local;
   psp_bin(blockIdx.x, s, local);
   const int b = blockIdx.y;
@@ -124,43 +125,71 @@ __global__ __launch_bounds__(128) void psp_pool_kernel(const float *__restrict__
   const int x0 = (j * W) / s, x1 = ((j + 1) * W + s - 1) / s;
   const float cnt = (float)((y1 - y0) * (x1 - x0));
   const int stage = s == 1 ? 0 : s == 2 ? 1 : s == 3 ? 2 : 3;
-  float *dst = out + ((size_t)psp_stage_off(stage) * B + (size_t)b * s * s + local) * C;
-  for (int c = threadIdx.x * 4; c < C; c += 128 * 4) {
+  float *dst = out + ((size_t)stage * B * 36 + (size_t)b * s * s + local) * C;
+  const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;         // 4 row-interleaved partial sums per channel vector
+  for (int c0 = 0; c0 < C; c0 += 128 * 4) {
+    const int c = c0 + tx * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int y = y0; y < y1; ++y)
-      for (int x = x0; x < x1; ++x) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(in + ((size_t)(b * H + y) * W + x) * in_ld + in_coff + c);
+    if (c < C)
+      for (int y = y0 + ty; y < y1; y += 4)
+        for (int x = x0; x < x1; ++x) {
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(in + ((size_t)(b * H + y) * W + x) * in_ld + in_coff + c);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += v[e];
-      }
+          for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        }
+    s_part[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+      f32x4 t = s_part[0][tx];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = acc[e] / cnt;
-    *reinterpret_cast<f32x4 *>(dst + c) = acc;
+      for (int q = 1; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] += s_part[q][tx][e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = t[e] / cnt;
+      *reinterpret_cast<f32x4 *>(dst + c) = t;
+    }
+    __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(TPB) void psp_upsample_concat_kernel(const float *__restrict__ stages,
-                                                                  float *__restrict__ out, int out_ld, int B, int H,
-                                                                  int W, int C) {
+// prior[b][y][x][c] = sum over the 4 pyramid stages of the bilinear (align_corners=False) resampling of
+// Z_s[b] (s x s x C) to (H, W): the PSP priors after the bottleneck 1x1 has been folded into the stage
+// weights (lib/pspnet.py:20-24; 1x1 conv and bilinear resampling are both linear and commute).
+__global__ __launch_bounds__(TPB) void psp_prior_sum_kernel(const float *__restrict__ z, float *__restrict__ out, int B,
+                                                            int H, int W, int C) {
   const int C4 = C / 4;
-  const long total = (long)B * H * W * 4 * C4;
+  const long total = (long)B * H * W * C4;
   for (long idx = blockIdx.x * (long)TPB + threadIdx.x; idx < total; idx += (long)gridDim.x * TPB) {
     const int c = (int)(idx % C4);
     long r = idx / C4;
-    const int stage = (int)(r % 4); r /= 4;
     const int x = (int)(r % W); r /= W;
     const int y = (int)(r % H);
     const int b = (int)(r / H);
-    const int s = stage == 0 ? 1 : stage == 1 ? 2 : stage == 2 ? 3 : 6;
-    int y0, y1, x0, x1;
-    float wy0, wy1, wx0, wx1;
-    src_hp(y, (float)s / (float)H, s, y0, y1, wy0, wy1);
-    src_hp(x, (float)s / (float)W, s, x0, x1, wx0, wx1);
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(stages + ((size_t)psp_stage_off(stage) * B + (size_t)b * s * s) * C);
-    const f32x4 v00 = src[(y0 * s + x0) * C4 + c], v01 = src[(y0 * s + x1) * C4 + c];
-    const f32x4 v10 = src[(y1 * s + x0) * C4 + c], v11 = src[(y1 * s + x1) * C4 + c];
-    *reinterpret_cast<f32x4 *>(out + ((size_t)(b * H + y) * W + x) * out_ld + stage * C + c * 4) =
-        lerp4(v00, v01, v10, v11, wy0, wy1, wx0, wx1);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int stage = 0; stage < 4; ++stage) {
+      const int s = stage == 0 ? 1 : stage == 1 ? 2 : stage == 2 ? 3 : 6;
+      int y0, y1, x0, x1;
+      float wy0, wy1, wx0, wx1;
+      src_hp(y, (float)s / (float)H, s, y0, y1, wy0, wy1);
+      src_hp(x, (float)s / (float)W, s, x0, x1, wx0, wx1);
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(z + ((size_t)stage * B * 36 + (size_t)b * s * s) * C);
+      const f32x4 v00 = src[(y0 * s + x0) * C4 + c], v01 = src[(y0 * s + x1) * C4 + c];
+      const f32x4 v10 = src[(y1 * s + x0) * C4 + c], v11 = src[(y1 * s + x1) * C4 + c];
+      const f32x4 v = lerp4(v00, v01, v10, v11, wy0, wy1, wx0, wx1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+    reinterpret_cast<f32x4 *>(out)[idx] = acc;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void transpose2d_kernel(const float *__restrict__ in, float *__restrict__ out, int R, int Cc) {
+  const long total = (long)R * Cc;
+  for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const long r = i / Cc, c = i - r * Cc;
+    out[c * R + r] = in[i];
   }
 }
 
@@ -356,11 +385,13 @@ void launch_upsample2x_ac(const float *in, float *out, int B, int H, int W, int 
                      H, W, C / 4);
 }
 void launch_psp_pool(const float *in, int in_ld, int in_coff, float *out, int B, int H, int W, int C, hipStream_t st) {
-  hipLaunchKernelGGL(psp_pool_kernel, dim3(50, B), dim3(128), 0, st, in, in_ld, in_coff, out, B, H, W, C);
+  hipLaunchKernelGGL(psp_pool_kernel, dim3(50, B), dim3(512), 0, st, in, in_ld, in_coff, out, B, H, W, C);
 }
-void launch_psp_upsample_concat(const float *stages, float *out, int out_ld, int B, int H, int W, int C, hipStream_t st) {
-  hipLaunchKernelGGL(psp_upsample_concat_kernel, dim3(blocks_for((long)B * H * W * C)), dim3(TPB), 0, st, stages, out,
-                     out_ld, B, H, W, C);
+void launch_psp_prior_sum(const float *z, float *out, int B, int H, int W, int C, hipStream_t st) {
+  hipLaunchKernelGGL(psp_prior_sum_kernel, dim3(blocks_for((long)B * H * W * (C / 4))), dim3(TPB), 0, st, z, out, B, H, W, C);
+}
+void launch_transpose2d(const float *in, float *out, int R, int C, hipStream_t st) {
+  hipLaunchKernelGGL(transpose2d_kernel, dim3(blocks_for((long)R * C)), dim3(TPB), 0, st, in, out, R, C);
 }
 void launch_gather_final_logsoftmax(const float *feat, const int64_t *choose, const float *w, const float *bias,
                                     float *emb, float *emb_pm, int B, int HW, int N, int Npad, hipStream_t st) {
