@@ -11,7 +11,7 @@ def main():
     bench.CROPS[:] = [(H, W)]
     dev = torch.device("cuda", 0)
     est, ref = bench.load_nets(dev)
-    pe = bench.PoseEstimator(est, ref)
+    pe = [bench.PoseEstimator(est, ref)]
     buckets = bench.make_buckets(0, 1, B, dev)
     for _ in range(3):
         bench.run_step(pe, buckets)
