@@ -203,6 +203,13 @@ static int load_param(Net &n, const std::string &key, const float *src, int64_t 
       hipDeviceSynchronize();
       hipFree(tmp);
     }
+    if (e == hipSuccess && key.find(".up_") != std::string::npos && HW == 9) {
+      // PSPUpsample convs run as low-resolution 1x1 products per tap: keep a tap-major copy [9][O][I]
+      float *tm = dev_alloc(n, key + ".tm", (size_t)9 * O * I);
+      if (!tm) return set_error(DF_ERR_LAUNCH, "load_param: hipMalloc failed");
+      launch_tapmajor(dst, tm, O, I, 0);
+      hipDeviceSynchronize();
+    }
   } else if (n.kind == 0 && key.rfind("conv1_", 0) == 0) {
     // head layer 1 of tower h: split [640][1408] into the per-point part (first 384 input channels =
     // pointfeat_1|pointfeat_2) and the broadcast global-feature part (last 1024), towers stacked r,t,c
@@ -413,23 +420,24 @@ static float *cnn_forward(Ctx &c, int B, int H, int W, const float *img, int &ou
     p.res = prior; p.res_ld = 1024;
     c.conv(p);
   }
-  // three x2 upsample + 3x3 conv + PReLU stages (lib/pspnet.py:27-37,69-75; dropout = identity in eval)
+  // three PSPUpsample stages (lib/pspnet.py:27-37,69-75; dropout = identity in eval), each as a low-resolution
+  // GEMM with N = 9*Cout followed by the 9-tap interpolation (layers.hip).  The last stage's interpolation is
+  // done only at the chosen pixels, inside the gather kernel, so the full-resolution map is never formed.
   float *cur = psp;
   const char *ups[3] = {"up_1", "up_2", "up_3"};
   const int up_in[3] = {1024, 256, 64}, up_out[3] = {256, 64, 64};
   for (int u = 0; u < 3; ++u) {
-    float *big = c.f((size_t)B * 4 * h * w * up_in[u]);
-    if (c.live()) launch_upsample2x_ac(cur, big, B, h, w, up_in[u], c.st);
+    float *y = c.f((size_t)B * h * w * 9 * up_out[u]);
+    c.conv(point_gemm(cur, up_in[u], 0, up_in[u], c.w(P + ups[u] + ".conv.1.weight.tm"), nullptr, y, 9 * up_out[u], 0, 9 * up_out[u],
+                      B * h * w, ACT_NONE));
+    if (u == 2) { outH = h; outW = w; return y; }      // y3 [B][h][w][576]; consumer interpolates at chosen pixels
+    float *o = c.f((size_t)B * 4 * h * w * up_out[u]);
+    if (c.live())
+      launch_upconv_gather(y, c.w(P + ups[u] + ".conv.1.bias"), c.w(P + ups[u] + ".conv.2.weight"), o, B, h, w, up_out[u], c.st);
     h *= 2; w *= 2;
-    float *o = c.f((size_t)B * h * w * up_out[u]);
-    ConvParams p = conv2d(big, B, h, w, up_in[u], up_in[u], c.w(P + ups[u] + ".conv.1.weight"), c.w(P + ups[u] + ".conv.1.bias"), o, h, w,
-                          up_out[u], up_out[u], 0, 3, 1, 1, 1, ACT_PRELU);
-    p.prelu = c.w(P + ups[u] + ".conv.2.weight");
-    c.conv(p);
     cur = o;
   }
-  outH = h; outW = w;
-  return cur;   // [B][h][w][64], the input of final.0
+  return cur;
 }
 
 // PoseNetFeat + heads (lib/network.py:53-68,107-131) on point-major rows padded to Npad per object
@@ -484,11 +492,12 @@ static void posenet_forward(Ctx &c, int B, int H, int W, const float *img, const
                             const int64_t *obj, PoseNetOut &o) {
   const int N = c.net->num_points, Npad = round_up(N, 128);
   int fh = 0, fw = 0;
-  float *feat = cnn_forward(c, B, H, W, img, fh, fw);
+  float *y3 = cnn_forward(c, B, H, W, img, fh, fw);      // fh x fw = the half-resolution grid of up_3's input
   o.emb_pm = c.f((size_t)B * Npad * 32);
   if (c.live())
-    launch_gather_final_logsoftmax(feat, choose, c.w(std::string(CNN) + "final.0.weight"), c.w(std::string(CNN) + "final.0.bias"),
-                                   o.emb, o.emb_pm, B, fh * fw, N, Npad, c.st);
+    launch_gather_final_logsoftmax(y3, c.w(std::string(CNN) + "up_3.conv.1.bias"), c.w(std::string(CNN) + "up_3.conv.2.weight"), choose,
+                                   c.w(std::string(CNN) + "final.0.weight"), c.w(std::string(CNN) + "final.0.bias"), o.emb,
+                                   o.emb_pm, B, fh, fw, N, Npad, c.st);
   posenet_points(c, B, N, Npad, cloud, o.emb_pm, obj, o.out_r, o.out_t, o.out_c);
 }
 

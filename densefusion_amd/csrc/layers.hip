@@ -193,31 +193,117 @@ __global__ __launch_bounds__(TPB) void transpose2d_kernel(const float *__restric
   }
 }
 
-// 8 points per workgroup pass: each 32-lane half-wave owns one point, lane = output channel.
-__global__ __launch_bounds__(TPB) void gather_final_lsm_kernel(const float *__restrict__ feat,
+// ---- "conv3x3 after bilinear x2" evaluated through the low-resolution per-tap products ----------------
+// PSPUpsample = Upsample(x2, align_corners=True) -> Conv3x3(pad 1) -> PReLU (lib/pspnet.py:27-37).  Both the
+// resampling and the convolution are linear:  conv(up(x))(P) = b + sum_tap W_tap . up(x)(P + tap)
+//                                                            = b + sum_tap up(W_tap . x)(P + tap),
+// with taps that fall outside the upsampled image contributing zero (the conv's zero padding).  So the
+// nine 1x1 products Y_tap = W_tap . x are taken at LOW resolution (one GEMM with N = 9*Cout, a quarter of
+// the conv's FLOPs) and this kernel does the 9-tap x 4-corner interpolation of Y at the output pixels.
+// y: [B][h][w][9*Cout] (tap-major channel blocks); out: [B][2h][2w][Cout].
+struct Tap3 { int i0[3], i1[3]; float w0[3], w1[3]; bool ok[3]; };
+__device__ inline Tap3 taps_for(int P, float scale, int in_size, int out_size) {
+  Tap3 t;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int q = P + d - 1;
+    t.ok[d] = (unsigned)q < (unsigned)out_size;
+    src_ac(t.ok[d] ? q : 0, scale, in_size, t.i0[d], t.i1[d], t.w0[d], t.w1[d]);
+  }
+  return t;
+}
+
+__global__ __launch_bounds__(TPB) void upconv_gather_kernel(const float *__restrict__ y, const float *__restrict__ bias,
+                                                            const float *__restrict__ prelu, float *__restrict__ out, int B,
+                                                            int h, int w, int Cout) {
+  const int OH = 2 * h, OW = 2 * w, C4 = Cout / 4, ldy = 9 * Cout;
+  const float sh = OH > 1 ? (float)(h - 1) / (float)(OH - 1) : 0.f;
+  const float sw = OW > 1 ? (float)(w - 1) / (float)(OW - 1) : 0.f;
+  const float slope = prelu[0];
+  const long total = (long)B * OH * OW * C4;
+  for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const int c = (int)(i % C4) * 4;
+    long r = i / C4;
+    const int px = (int)(r % OW); r /= OW;
+    const int py = (int)(r % OH);
+    const int b = (int)(r / OH);
+    const Tap3 ty = taps_for(py, sh, h, OH), tx = taps_for(px, sw, w, OW);
+    const float *yb = y + (size_t)b * h * w * ldy + c;
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(bias + c);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      if (!ty.ok[dy]) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        if (!tx.ok[dx]) continue;
+        const float *t = yb + (dy * 3 + dx) * Cout;
+        const f32x4 v00 = *reinterpret_cast<const f32x4 *>(t + (size_t)(ty.i0[dy] * w + tx.i0[dx]) * ldy);
+        const f32x4 v01 = *reinterpret_cast<const f32x4 *>(t + (size_t)(ty.i0[dy] * w + tx.i1[dx]) * ldy);
+        const f32x4 v10 = *reinterpret_cast<const f32x4 *>(t + (size_t)(ty.i1[dy] * w + tx.i0[dx]) * ldy);
+        const f32x4 v11 = *reinterpret_cast<const f32x4 *>(t + (size_t)(ty.i1[dy] * w + tx.i1[dx]) * ldy);
+        const f32x4 v = lerp4(v00, v01, v10, v11, ty.w0[dy], ty.w1[dy], tx.w0[dx], tx.w1[dx]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = acc[e] > 0.f ? acc[e] : acc[e] * slope;
+    reinterpret_cast<f32x4 *>(out)[i] = acc;
+  }
+}
+
+// Tail of the colour branch, only at the N chosen pixels (lib/network.py:98-102): up_3 (the interpolation
+// above, 64 channels, + bias + PReLU), then final 1x1 conv 64->32 + LogSoftmax (lib/pspnet.py:53-56).
+// 8 points per workgroup pass: each 32-lane half-wave owns one point; lane = 2 up_3 channels, then 1 output.
+__global__ __launch_bounds__(TPB) void gather_final_lsm_kernel(const float *__restrict__ y3, const float *__restrict__ bias3,
+                                                               const float *__restrict__ prelu3,
                                                                const int64_t *__restrict__ choose,
                                                                const float *__restrict__ w, const float *__restrict__ bias,
                                                                float *__restrict__ emb, float *__restrict__ emb_pm, int B,
-                                                               int HW, int N, int Npad) {
+                                                               int h, int wd, int N, int Npad) {
   __shared__ __attribute__((aligned(16))) float sx[8][64];
   const int tid = threadIdx.x;
   const int o = tid & 31, slot = tid >> 5;
+  const int OH = 2 * h, OW = 2 * wd, HW = OH * OW, ldy = 9 * 64;
+  const float sh = OH > 1 ? (float)(h - 1) / (float)(OH - 1) : 0.f;
+  const float sw = OW > 1 ? (float)(wd - 1) / (float)(OW - 1) : 0.f;
+  const float slope = prelu3[0];
   float wr[64];
 #pragma unroll
   for (int c = 0; c < 64; ++c) wr[c] = w[o * 64 + c];
   const float bo = bias[o];
+  const float2 b3 = *reinterpret_cast<const float2 *>(bias3 + o * 2);
   const long total = (long)B * N;
   for (long p0 = (long)blockIdx.x * 8; p0 < total; p0 += (long)gridDim.x * 8) {
-    {   // stage the 8 gathered 64-channel pixels: thread t loads 2 floats of point t/32
+    {
       const long p = p0 + slot;
-      float2 v = make_float2(0.f, 0.f);
+      float2 acc = b3;
       if (p < total) {
         const long b = p / N;
         long pix = choose[p];
         pix = pix < 0 ? 0 : (pix >= HW ? HW - 1 : pix);     // torch.gather would raise; clamp keeps the launch safe
-        v = *reinterpret_cast<const float2 *>(feat + ((size_t)b * HW + pix) * 64 + o * 2);
+        const int py = (int)(pix / OW), px = (int)(pix - (long)py * OW);
+        const Tap3 ty = taps_for(py, sh, h, OH), tx = taps_for(px, sw, wd, OW);
+        const float *yb = y3 + (size_t)b * h * wd * ldy + o * 2;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          if (!ty.ok[dy]) continue;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            if (!tx.ok[dx]) continue;
+            const float *t = yb + (dy * 3 + dx) * 64;
+            const float2 v00 = *reinterpret_cast<const float2 *>(t + (size_t)(ty.i0[dy] * wd + tx.i0[dx]) * ldy);
+            const float2 v01 = *reinterpret_cast<const float2 *>(t + (size_t)(ty.i0[dy] * wd + tx.i1[dx]) * ldy);
+            const float2 v10 = *reinterpret_cast<const float2 *>(t + (size_t)(ty.i1[dy] * wd + tx.i0[dx]) * ldy);
+            const float2 v11 = *reinterpret_cast<const float2 *>(t + (size_t)(ty.i1[dy] * wd + tx.i1[dx]) * ldy);
+            acc.x += ty.w0[dy] * (tx.w0[dx] * v00.x + tx.w1[dx] * v01.x) + ty.w1[dy] * (tx.w0[dx] * v10.x + tx.w1[dx] * v11.x);
+            acc.y += ty.w0[dy] * (tx.w0[dx] * v00.y + tx.w1[dx] * v01.y) + ty.w1[dy] * (tx.w0[dx] * v10.y + tx.w1[dx] * v11.y);
+          }
+        }
+        acc.x = acc.x > 0.f ? acc.x : acc.x * slope;
+        acc.y = acc.y > 0.f ? acc.y : acc.y * slope;
       }
-      *reinterpret_cast<float2 *>(&sx[slot][o * 2]) = v;
+      *reinterpret_cast<float2 *>(&sx[slot][o * 2]) = acc;
     }
     __syncthreads();
     float acc = bo;
@@ -227,11 +313,11 @@ __global__ __launch_bounds__(TPB) void gather_final_lsm_kernel(const float *__re
     float mx = acc;
 #pragma unroll
     for (int d = 16; d >= 1; d >>= 1) { const float t = __shfl_xor(mx, d); mx = t > mx ? t : mx; }
-    const float sh = acc - mx;
-    float se = expf(sh);
+    const float shf = acc - mx;
+    float se = expf(shf);
 #pragma unroll
     for (int d = 16; d >= 1; d >>= 1) se += __shfl_xor(se, d);
-    const float r = sh - logf(se);
+    const float r = shf - logf(se);
     const long p = p0 + slot;
     if (p < total) {
       const long b = p / N, n = p - b * N;
@@ -239,6 +325,18 @@ __global__ __launch_bounds__(TPB) void gather_final_lsm_kernel(const float *__re
       emb_pm[((size_t)b * Npad + n) * 32 + o] = r;
     }
     __syncthreads();
+  }
+}
+
+// conv weights [O][9][I] (OHWI) -> tap-major [9][O][I]
+__global__ __launch_bounds__(TPB) void tapmajor_kernel(const float *__restrict__ src, float *__restrict__ dst, int O, int I) {
+  const long total = (long)O * 9 * I;
+  for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const int c = (int)(i % I);
+    const long r = i / I;
+    const int t = (int)(r % 9);
+    const long o = r / 9;
+    dst[((size_t)t * O + o) * I + c] = src[i];
   }
 }
 
@@ -393,10 +491,19 @@ void launch_psp_prior_sum(const float *z, float *out, int B, int H, int W, int C
 void launch_transpose2d(const float *in, float *out, int R, int C, hipStream_t st) {
   hipLaunchKernelGGL(transpose2d_kernel, dim3(blocks_for((long)R * C)), dim3(TPB), 0, st, in, out, R, C);
 }
-void launch_gather_final_logsoftmax(const float *feat, const int64_t *choose, const float *w, const float *bias,
-                                    float *emb, float *emb_pm, int B, int HW, int N, int Npad, hipStream_t st) {
-  hipLaunchKernelGGL(gather_final_lsm_kernel, dim3(blocks_for((long)B * N * 32)), dim3(TPB), 0, st, feat, choose, w, bias,
-                     emb, emb_pm, B, HW, N, Npad);
+void launch_gather_final_logsoftmax(const float *y3, const float *bias3, const float *prelu3, const int64_t *choose,
+                                    const float *w, const float *bias, float *emb, float *emb_pm, int B, int h, int wd, int N,
+                                    int Npad, hipStream_t st) {
+  hipLaunchKernelGGL(gather_final_lsm_kernel, dim3(blocks_for((long)B * N * 32)), dim3(TPB), 0, st, y3, bias3, prelu3, choose,
+                     w, bias, emb, emb_pm, B, h, wd, N, Npad);
+}
+void launch_upconv_gather(const float *y, const float *bias, const float *prelu, float *out, int B, int h, int w, int Cout,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(upconv_gather_kernel, dim3(blocks_for((long)B * 4 * h * w * (Cout / 4))), dim3(TPB), 0, st, y, bias, prelu,
+                     out, B, h, w, Cout);
+}
+void launch_tapmajor(const float *src, float *dst, int O, int I, hipStream_t st) {
+  hipLaunchKernelGGL(tapmajor_kernel, dim3(blocks_for((long)O * 9 * I)), dim3(TPB), 0, st, src, dst, O, I);
 }
 void launch_emb_to_pm(const float *emb, float *emb_pm, int B, int N, int Npad, hipStream_t st) {
   hipLaunchKernelGGL(emb_to_pm_kernel, dim3(blocks_for((long)B * N * 32)), dim3(TPB), 0, st, emb, emb_pm, B, N, Npad);
