@@ -210,12 +210,19 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const ConvParams p) {
 // ------------------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT>
 __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;
+  // BKT = k depth of one LDS tile (32 or 64): the MFMA time between two barriers is BKT/2 * TM*TN * 64 cycles,
+  // so the small 64x64 tile takes BKT = 64 to keep the barrier cost per MFMA where the 128x128 tile has it.
+  constexpr int VPR = BKT / 4;                  // 16-byte vectors per tile row
+  constexpr int RPP = 256 / VPR;                // tile rows staged per pass of the 256 threads
+  constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;
+  constexpr int LDK = BKT + 4;                  // padded row: ds_read_b128 of 16 rows hits 64 distinct banks
+  constexpr int BK = BKT;
+  constexpr int NP = BKT / 16;                  // pairs of 8-wide k groups per tile
   constexpr int TILE = (BM + BN) * LDK;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -246,11 +253,11 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
                                                       (unsigned)((size_t)p.Cout * K * sizeof(float)), 0x00020000);
   const int in_c0 = p.in_coff + (int)(z * p.z_in_coff);
 
-  const int vec = tid & 7, lrow = tid >> 3;
+  const int vec = tid % VPR, lrow = tid / VPR;
   int a_iy0[A_ROWS], a_ix0[A_ROWS], a_off[A_ROWS];   // a_off: element offset of (b, iy0, ix0, first channel)
 #pragma unroll
   for (int i = 0; i < A_ROWS; ++i) {
-    const int m = m0 + lrow + 32 * i;
+    const int m = m0 + lrow + RPP * i;
     if (m < M) {
       const int ohw = p.OH * p.OW;
       const int b = m / ohw, rem = m - b * ohw;
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
   int b_off[B_ROWS];
 #pragma unroll
   for (int i = 0; i < B_ROWS; ++i) {
-    const int n = n0 + lrow + 32 * i;
+    const int n = n0 + lrow + RPP * i;
     b_off[i] = n < p.Cout ? n * K : -1;
   }
   const bool one_tap = (p.KH * p.KW == 1);
@@ -281,6 +288,9 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
 
   u32x4 ra[A_ROWS], rb[B_ROWS];
   auto issue_loads = [&](int kt) {
+    // the tile index goes through an opaque asm so that the address arithmetic below cannot be strength-reduced
+    // into loop-header induction updates: it has to stay here, between the MFMAs, where its issue slots are free
+    asm volatile("" : "+s"(kt));
     const int k = kt * BK + vec * 4;
     const int kok = k < K;
     const int tap = k >> k_shift;
@@ -308,9 +318,9 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
   auto write_lds = [&](int buf) {
     float *sA = smem + buf * TILE, *sB = sA + BM * LDK;
 #pragma unroll
-    for (int i = 0; i < A_ROWS; ++i) *reinterpret_cast<u32x4 *>(sA + (lrow + 32 * i) * LDK + vec * 4) = ra[i];
+    for (int i = 0; i < A_ROWS; ++i) *reinterpret_cast<u32x4 *>(sA + (lrow + RPP * i) * LDK + vec * 4) = ra[i];
 #pragma unroll
-    for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<u32x4 *>(sB + (lrow + 32 * i) * LDK + vec * 4) = rb[i];
+    for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<u32x4 *>(sB + (lrow + RPP * i) * LDK + vec * 4) = rb[i];
   };
 
   const int li = lane & 31, lh = lane >> 5;
@@ -354,18 +364,37 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
   read_frags(0, 0, a0, b0);
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
-    mfma_group(a0[0], b0[0]);
-    mfma_group(a0[1], b0[1]);
-    read_frags(buf, 1, a1, b1);
-    // Keep the register -> LDS hand-over of tile kt+1 and the issue of tile kt+2 in the third quarter:
-    // the loads then have a full tile of MFMA time (~4k cycles) to land before their ds_write.
-    __builtin_amdgcn_sched_barrier(0);
-    write_lds(buf ^ 1);               // tile kt+1 (zeros past the end): registers -> the idle buffer
-    issue_loads(kt + 2);              // tile kt+2 starts its trip; consumed one full tile later
-    mfma_group(a1[0], b1[0]);
-    __syncthreads();                  // everyone has read tile kt out of `buf`; tile kt+1 is complete in buf^1
-    read_frags(buf ^ 1, 0, a0, b0);   // lands while the last quarter of tile kt multiplies
+    // pair pp multiplies out of register set pp&1 while pair pp+1 is read into the other set
+#pragma unroll
+    for (int pp = 0; pp < NP - 1; ++pp) {
+      if (pp & 1) read_frags(buf, pp + 1, a0, b0); else read_frags(buf, pp + 1, a1, b1);
+      if (pp == NP / 2 - 1) {
+        // register -> LDS hand-over of tile kt+1 and the issue of tile kt+2 sit mid-tile: the loads then have
+        // about a full tile of MFMA time to land before their ds_write
+        __builtin_amdgcn_sched_barrier(0);
+        write_lds(buf ^ 1);             // tile kt+1 (zeros past the end): registers -> the idle buffer
+        issue_loads(kt + 2);            // tile kt+2 starts its trip; consumed one full tile later
+      }
+      if (pp & 1) { mfma_group(a1[0], b1[0]); mfma_group(a1[1], b1[1]); }
+      else { mfma_group(a0[0], b0[0]); mfma_group(a0[1], b0[1]); }
+      if (pp == NP / 2 - 1) {
+        // Spread the loader's address arithmetic, the ds_writes and the buffer loads evenly over the MFMAs of
+        // this pair: an f32 MFMA keeps the matrix pipe busy for 64 cycles, during which the same wave can issue
+        // ~10 other instructions for free -- but a run of 40 of them between two MFMAs leaves the pipe idle.
+#pragma unroll
+        for (int q = 0; q < 8 * TM * TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, TM * TN == 4 ? 3 : 8, 0);     // VALU
+          __builtin_amdgcn_sched_group_barrier(0x004, TM * TN == 4 ? 1 : 3, 0);     // SALU
+          __builtin_amdgcn_sched_group_barrier(0x090, TM * TN == 4 ? 1 : 2, 0);     // DS | VMEM
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();                    // everyone has read tile kt out of `buf`; tile kt+1 is complete in buf^1
+    read_frags(buf ^ 1, 0, a0, b0);     // lands while the last pair of tile kt multiplies
     __builtin_amdgcn_sched_barrier(0);  // hipcc would otherwise hoist these MFMAs above the barrier
+    mfma_group(a1[0], b1[0]);
     mfma_group(a1[1], b1[1]);
   }
   __syncthreads();                    // the speculative fragment reads above are done before smem is reused
@@ -387,7 +416,7 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
   const int grp = (p.rows_per_group > 0) ? m0 / p.rows_per_group : 0;
   const float *bias = p.bias ? p.bias + z * p.z_bias + (p.bias_group_ld > 0 ? (size_t)grp * p.bias_group_ld : 0) : nullptr;
   constexpr int LPR = WN / 4;            // lanes per row
-  constexpr int RPP = 64 / LPR;          // rows per pass
+  constexpr int ERPP = 64 / LPR;         // rows per pass
   const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
   const int n = n0 + wn * WN + c4;
   const bool nok = n < p.Cout;           // Cout % 4 == 0 (host-checked): a vector is all-in or all-out
@@ -395,8 +424,8 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
   if (bias && nok) bv = *reinterpret_cast<const f32x4 *>(bias + n);
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-  for (int ps = 0; ps < WM / RPP; ++ps) {
-    const int row = ps * RPP + r0;
+  for (int ps = 0; ps < WM / ERPP; ++ps) {
+    const int row = ps * ERPP + r0;
     const int m = m0 + wm * WM + row;
     const bool ok = nok && m < M;
     f32x4 v = *reinterpret_cast<const f32x4 *>(ep + row * EP_LD + c4);
@@ -436,9 +465,8 @@ struct TileCfg { int bm, bn, wmv; };
 
 TileCfg pick_cfg(const ConvParams &p) {
   const long M = (long)p.B * p.OH * p.OW;
-  // Row-grouped launches (fused mean / per-object bias) need BM | rows_per_group: always 128x128.
-  if (p.rows_per_group > 0) return {128, 128, 2};
-  // Otherwise pick the tile that minimises  ceil(tiles / 256 CUs) * tile_area / efficiency : the chip
+  // (Row-grouped launches -- fused mean / per-object bias -- need BM | rows_per_group; both tiles divide the
+  // 128-padded groups the engine uses.)  Pick the tile that minimises  ceil(tiles / 256 CUs) * tile_area / efficiency : the chip
   // finishes when its most loaded CU does, so a 128x128 grid of e.g. 800 tiles (4 rounds for 3.1 rounds
   // of work) loses to the same problem cut into 3200 64x64 tiles (13 rounds for 12.5).
   auto cost = [&](int bm, int bn, double eff) {
@@ -446,7 +474,7 @@ TileCfg pick_cfg(const ConvParams &p) {
     const long rounds = (tiles + 255) / 256;
     return (double)rounds * bm * bn / eff;
   };
-  const double c128 = cost(128, 128, 1.0), c64 = cost(64, 64, 0.96);
+  const double c128 = cost(128, 128, 1.0), c64 = cost(64, 64, 0.94);
   if (p.Cout >= 128 && c128 <= c64) return {128, 128, 2};
   return {64, 64, 2};
 }
@@ -494,14 +522,19 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
   if (v2) {
     static bool attr2 = false;
     if (!attr2) {
-      hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_f32_v2_kernel<128, 128, 2, 2>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * LDK * (int)sizeof(float));
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_f32_v2_kernel<128, 128, 2, 2, 32>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 36 * (int)sizeof(float));
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_f32_v2_kernel<64, 64, 2, 2, 64>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 68 * (int)sizeof(float));
       attr2 = true;
     }
+    const bool bk32 = getenv("DF_IGEMM_BK64") == nullptr;      // dev switch: BK=64 measured slower on most 64x64 shapes
     if (c.bm == 128)
-      hipLaunchKernelGGL((igemm_f32_v2_kernel<128, 128, 2, 2>), grid, dim3(256), lds, st, p);
+      hipLaunchKernelGGL((igemm_f32_v2_kernel<128, 128, 2, 2, 32>), grid, dim3(256), (size_t)2 * 256 * 36 * sizeof(float), st, p);
+    else if (bk32)
+      hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2, 32>), grid, dim3(256), (size_t)2 * 128 * 36 * sizeof(float), st, p);
     else
-      hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2>), grid, dim3(256), lds, st, p);
+      hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2, 64>), grid, dim3(256), (size_t)2 * 128 * 68 * sizeof(float), st, p);
   } else if (c.bm == 128) {
     hipLaunchKernelGGL((igemm_f32_kernel<128, 128, 2, 2>), grid, dim3(256), lds, st, p);
   } else {
