@@ -43,6 +43,8 @@ SIGNATURES = {
     "df_loss_forward": (_i, [_vp] * 6 + [_i, _i, _f, _i] + [_vp] * 6),
     "df_loss_refine_forward": (_i, [_vp] * 5 + [_i, _i, _i] + [_vp] * 4),
     "df_add_metric": (_i, [_vp] * 4 + [_i, _i, _vp, _vp]),
+    "df_ycb_distances": (_i, [_vp] * 3 + [_i, _i, _vp, _vp, _vp]),
+    "df_preprocess_objects": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "df_conv2d_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp]),
     "df_net_profile": (_i, [_vp, _i]),
     "df_net_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i)]),

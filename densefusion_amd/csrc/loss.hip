@@ -222,6 +222,50 @@ __global__ __launch_bounds__(LB) void add_metric_kernel(const double *__restrict
   if (tid == 0) out[b] = sym ? (double)((float)s_red[0] / (float)M) : s_red[0] / (double)M;
 }
 
+// YCB-Video toolbox distances (replace_ycb_toolbox/evaluate_poses_keyframe.m:160-193), fp64 like MATLAB:
+//   add = mean_m || RT_est p_m - RT_gt p_m ||
+//   adi = mean_m  min_j || RT_est p_j - RT_gt p_m ||     (nearest ESTIMATED point for every GT point --
+//                                                         the opposite direction to tools/eval_linemod.py)
+// rt: [B][12] = 3x4 row-major [R|t]; pts: [B][M][3] fp64.  One workgroup per object, est points in LDS.
+__global__ __launch_bounds__(LB) void ycb_dist_kernel(const double *__restrict__ rt_est, const double *__restrict__ rt_gt,
+                                                      const double *__restrict__ pts, int M, double *__restrict__ add_out,
+                                                      double *__restrict__ adi_out) {
+  extern __shared__ __attribute__((aligned(16))) double s_est[];   // [M][3]
+  __shared__ double s_red[2][LB];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const double *E = rt_est + b * 12, *G = rt_gt + b * 12, *P = pts + (size_t)b * M * 3;
+  for (int m = tid; m < M; m += LB) {
+    const double x = P[m * 3], y = P[m * 3 + 1], z = P[m * 3 + 2];
+    s_est[m * 3 + 0] = E[0] * x + E[1] * y + E[2] * z + E[3];
+    s_est[m * 3 + 1] = E[4] * x + E[5] * y + E[6] * z + E[7];
+    s_est[m * 3 + 2] = E[8] * x + E[9] * y + E[10] * z + E[11];
+  }
+  __syncthreads();
+  double a_add = 0.0, a_adi = 0.0;
+  for (int m = tid; m < M; m += LB) {
+    const double x = P[m * 3], y = P[m * 3 + 1], z = P[m * 3 + 2];
+    const double gx = G[0] * x + G[1] * y + G[2] * z + G[3];
+    const double gy = G[4] * x + G[5] * y + G[6] * z + G[7];
+    const double gz = G[8] * x + G[9] * y + G[10] * z + G[11];
+    const double dx = s_est[m * 3] - gx, dy = s_est[m * 3 + 1] - gy, dz = s_est[m * 3 + 2] - gz;
+    a_add += sqrt(dx * dx + dy * dy + dz * dz);
+    double best = __builtin_inf();
+    for (int j = 0; j < M; ++j) {
+      const double ex = s_est[j * 3] - gx, ey = s_est[j * 3 + 1] - gy, ez = s_est[j * 3 + 2] - gz;
+      const double d = ex * ex + ey * ey + ez * ez;
+      best = d < best ? d : best;
+    }
+    a_adi += sqrt(best);
+  }
+  s_red[0][tid] = a_add; s_red[1][tid] = a_adi;
+  __syncthreads();
+  for (int d = LB / 2; d >= 1; d >>= 1) {
+    if (tid < d) { s_red[0][tid] += s_red[0][tid + d]; s_red[1][tid] += s_red[1][tid + d]; }
+    __syncthreads();
+  }
+  if (tid == 0) { add_out[b] = s_red[0][0] / (double)M; adi_out[b] = s_red[1][0] / (double)M; }
+}
+
 int check_m(int M, const char *what) {
   if (M <= 0 || (size_t)M * 16 > 150 * 1024) return set_error(DF_ERR_ARG, "%s: num_points_mesh must be in [1, 9600] (got %d)", what, M);
   return DF_OK;
@@ -289,4 +333,17 @@ extern "C" int df_add_metric(const double *pose, const float *model_points, cons
   }
   hipLaunchKernelGGL(add_metric_kernel, dim3(B), dim3(LB), (size_t)M * 16, to_stream(stream), pose, model_points, target, symmetric, M, dis_out);
   return check_launch("add_metric");
+}
+
+extern "C" int df_ycb_distances(const double *rt_est, const double *rt_gt, const double *pts, int B, int M, double *add_out,
+                                double *adi_out, df_stream_t stream) {
+  if (!rt_est || !rt_gt || !pts || !add_out || !adi_out) return set_error(DF_ERR_ARG, "ycb_distances: null pointer");
+  if (B <= 0 || M <= 0 || (size_t)M * 24 > 150 * 1024) return set_error(DF_ERR_ARG, "ycb_distances: need B >= 1 and 1 <= M <= 6400");
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&ycb_dist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(ycb_dist_kernel, dim3(B), dim3(LB), (size_t)M * 24, to_stream(stream), rt_est, rt_gt, pts, M, add_out, adi_out);
+  return check_launch("ycb_distances");
 }

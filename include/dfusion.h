@@ -120,6 +120,27 @@ int df_loss_refine_forward(const float *pred_r, const float *pred_t, const float
                            float *new_target, df_stream_t stream);
 int df_add_metric(const double *pose, const float *model_points, const float *target, const int *symmetric, int B,
                   int M, double *dis_out, df_stream_t stream);
+/* YCB-Video toolbox distances (replace_ycb_toolbox/evaluate_poses_keyframe.m:160-193), fp64 like MATLAB:
+ * rt_est / rt_gt [B][12] = 3x4 row-major [R|t], pts [B][M][3] fp64 model points ->
+ * add_out [B] = mean ||est_m - gt_m||,  adi_out [B] = mean_m min_j ||est_j - gt_m|| (KDTreeSearcher direction). */
+int df_ycb_distances(const double *rt_est, const double *rt_gt, const double *pts, int B, int M, double *add_out,
+                     double *adi_out, df_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Input preparation on the device (the numpy block of tools/eval_ycb.py:147-181, per detected object):
+ * mask = (depth != 0) & (label == itemid) inside the snapped box; choose = num_points mask pixels (random
+ * subset / wrap-padding); back-projected cloud; ImageNet-normalised CHW crop.  B objects of one crop size
+ * (H x W) per call.
+ *   rgb [F][IH][IW][3] u8, depth [F][IH][IW] u16, label [F][IH][IW] i32 (F frames resident on the device)
+ *   obj_desc [B][8] int32 = {frame, itemid, rmin, rmax, cmin, cmax, seed, 0}; rmax-rmin == H, cmax-cmin == W
+ *   scratch: B*H*W int32.  Outputs: img_out [B][3][H][W], cloud_out [B][N][3], choose_out [B][N] int64,
+ *   count_out [B] = number of mask pixels (0 = detector lost the object, eval_ycb.py:234-237).
+ * Subset rule when count > N (replaces np.random.shuffle, whose stream a GPU cannot share): keep the N mask
+ * pixels with the smallest mix32(seed, flat index) keys, in index order -- a uniformly random ordered subset. */
+int df_preprocess_objects(const unsigned char *rgb, const unsigned short *depth, const int *label, int num_frames, int IH,
+                          int IW, const int *obj_desc, int B, int H, int W, int num_points, float cam_cx, float cam_cy,
+                          float cam_fx, float cam_fy, float cam_scale, int *scratch, float *img_out, float *cloud_out,
+                          int64_t *choose_out, int *count_out, df_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Building block, exposed for unit parity tests and for callers that want single layers: channels-last
