@@ -98,17 +98,28 @@ def profile_gemm(pe, buckets, steps):
     L = _lib.lib()
     hp, hr = pe[0].estimator._handle, pe[0].refiner._handle
     L.df_net_profile(hp, 1); L.df_net_profile(hr, 1)
-    tot_ms = tot_fl = 0.0
+    tot_ms = tot_fl = tot_by = 0.0
     tot_n = 0
     for _ in range(steps):
         run_step(pe, buckets)
         torch.cuda.synchronize()
         for h in (hp, hr):
-            ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-            _lib.check(L.df_net_profile_read(h, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "profile_read")
-            tot_ms += ms.value; tot_fl += fl.value; tot_n += n.value
+            ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+            _lib.check(L.df_net_profile_read(h, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n)), "profile_read")
+            tot_ms += ms.value; tot_fl += fl.value; tot_by += by.value; tot_n += n.value
     L.df_net_profile(hp, 0); L.df_net_profile(hr, 0)
-    return tot_ms, tot_fl, tot_n
+    return tot_ms, tot_fl, tot_by, tot_n
+
+
+def measured_traffic():
+    """HBM bytes per igemm launch from the committed PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE,
+    profiles/r01_igemm_traffic.json); None when the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_igemm_traffic.json")) as f:
+            t = json.load(f)
+        return {"hbm_mb_per_launch": round(t["avg_hbm_bytes_per_launch"] / 1e6, 2), "source": "profiles/r01_igemm_traffic.json (rocprofv3 --pmc, serial un-graphed run)"}
+    except Exception:   # noqa: BLE001
+        return None
 
 
 def bench_knn():
@@ -280,11 +291,13 @@ def main():
                                "executes fewer (PSP fold, low-resolution up-convs, head fold), so that rate may exceed the fp32 peak"},
             "reference_algorithm_tflops_per_gpu": round(gflop_step * args.steps / dt / 1e3, 2),
         }
-        ms, fl, n = profile_gemm(pe, buckets, min(args.steps, 5))
+        ms, fl, by, n = profile_gemm(pe, buckets, min(args.steps, 5))
+        traffic = measured_traffic()
         ach = fl / ms / 1e9 if ms > 0 else 0.0
         out["roofline"] = {"kernel": "igemm_f32_kernel (implicit-GEMM conv / per-point GEMM, v_mfma_f32_32x32x2_f32)",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+                           "algorithmic_mb_per_launch": round(by / max(n, 1) / 1e6, 2),
                            "launches_per_step": n // max(1, min(args.steps, 5)),
                            "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
                            "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),

@@ -40,7 +40,7 @@ struct Net {
   // profiling of GEMM launches (bench.py roofline): event pairs around every launch_conv
   bool profiling = false;
   std::vector<hipEvent_t> ev;
-  std::vector<double> ev_flops;
+  std::vector<double> ev_flops, ev_bytes;
   std::vector<std::string> ev_desc;
   size_t ev_used = 0;
 };
@@ -312,6 +312,7 @@ struct Ctx {
     if (n.profiling) {
       hipEventRecord(n.ev[n.ev_used + 1], st);
       n.ev_flops.push_back(conv_flops(p));
+      n.ev_bytes.push_back(conv_bytes(p));
       char d[160];
       snprintf(d, sizeof(d), "M=%ld N=%d K=%d k%dx%d s%d d%d z%d", (long)p.B * p.OH * p.OW, p.Cout, p.KH * p.KW * p.Cin, p.KH,
                p.KW, p.stride, p.dil, p.zcount);
@@ -611,28 +612,32 @@ extern "C" int df_net_profile(df_net *h, int enable) {
   n->profiling = enable != 0;
   n->ev_used = 0;
   n->ev_flops.clear();
+  n->ev_bytes.clear();
   n->ev_desc.clear();
   return DF_OK;
 }
 
 // after a stream sync: sum of GEMM launch durations (ms), their algorithmic FLOPs and count since df_net_profile(1)
-extern "C" int df_net_profile_read(df_net *h, double *gemm_ms, double *gemm_flops, int *launches) {
+extern "C" int df_net_profile_read(df_net *h, double *gemm_ms, double *gemm_flops, double *gemm_bytes, int *launches) {
   if (!h) return set_error(DF_ERR_ARG, "profile_read: null handle");
   Net *n = as_net(h);
-  double ms = 0, fl = 0;
+  double ms = 0, fl = 0, by = 0;
   for (size_t i = 0; i + 1 < n->ev_used; i += 2) {
     float t = 0;
     if (hipEventElapsedTime(&t, n->ev[i], n->ev[i + 1]) != hipSuccess) return set_error(DF_ERR_LAUNCH, "profile_read: events not complete");
     ms += t;
     fl += n->ev_flops[i / 2];
+    by += n->ev_bytes[i / 2];
     if (getenv("DF_PROFILE_VERBOSE"))
       fprintf(stderr, "[df-gemm] %s  %.1f us  %.1f TFLOP/s\n", n->ev_desc[i / 2].c_str(), t * 1e3, n->ev_flops[i / 2] / t / 1e9);
   }
   if (gemm_ms) *gemm_ms = ms;
   if (gemm_flops) *gemm_flops = fl;
+  if (gemm_bytes) *gemm_bytes = by;
   if (launches) *launches = (int)(n->ev_used / 2);
   n->ev_used = 0;
   n->ev_flops.clear();
+  n->ev_bytes.clear();
   n->ev_desc.clear();
   return DF_OK;
 }

@@ -35,6 +35,8 @@ struct ConvParams {
 int conv_colsum_rows(const ConvParams &p);
 // FLOPs (2*MAC) of the launch, algorithmic (no padding)
 double conv_flops(const ConvParams &p);
+// algorithmic HBM bytes (inputs, weights, outputs and residual touched once)
+double conv_bytes(const ConvParams &p);
 int launch_conv(const ConvParams &p, hipStream_t st);
 
 }  // namespace df

@@ -487,6 +487,13 @@ int conv_colsum_rows(const ConvParams &p) {
   return (int)(((M + c.bm - 1) / c.bm) * c.wmv) * p.zcount;
 }
 
+double conv_bytes(const ConvParams &p) {
+  // algorithmic HBM bytes of one launch: every input element, weight and output element once (+ residual)
+  const double M = (double)p.B * p.OH * p.OW;
+  double b = (double)p.B * p.H * p.W * p.Cin + (double)p.Cout * p.KH * p.KW * p.Cin + (p.out ? M * p.Cout : 0.0) + (p.res ? M * p.Cout : 0.0);
+  return b * p.zcount * sizeof(float);
+}
+
 double conv_flops(const ConvParams &p) {
   return 2.0 * p.B * p.OH * p.OW * (double)p.Cout * p.KH * p.KW * p.Cin * p.zcount;
 }

@@ -162,9 +162,10 @@ int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream);
 
 /* Per-launch timing of the GEMM kernel with HIP events on the call's stream (bench.py roofline).
  * df_net_profile(net, 1) arms it; after the stream has been synchronised df_net_profile_read returns the
- * summed duration (ms), the algorithmic FLOPs and the number of GEMM launches since arming, and re-arms. */
+ * summed duration (ms), the algorithmic FLOPs, the algorithmic HBM bytes (each input, weight, output element once) and
+ * the number of GEMM launches since arming, and re-arms. */
 int df_net_profile(df_net *net, int enable);
-int df_net_profile_read(df_net *net, double *gemm_ms, double *gemm_flops, int *launches);
+int df_net_profile_read(df_net *net, double *gemm_ms, double *gemm_flops, double *gemm_bytes, int *launches);
 
 #ifdef __cplusplus
 }

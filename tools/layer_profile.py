@@ -16,7 +16,7 @@ def main():
     for _ in range(3):
         bench.run_step(pe, buckets)
     torch.cuda.synchronize()
-    ms, fl, n = bench.profile_gemm(pe, buckets, 1)
+    ms, fl, by, n = bench.profile_gemm(pe, buckets, 1)
     print(f"total gemm {ms:.3f} ms, {fl/ms/1e9:.1f} TFLOP/s, {n} launches")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
