@@ -40,8 +40,10 @@ SIGNATURES = {
     "df_refiner_forward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "df_estimate_workspace_bytes": (_sz, [_vp, _vp, _i, _i, _i]),
     "df_estimate_poses": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
-    "df_loss_forward": (_i, [_vp] * 6 + [_i, _i, _f, _i] + [_vp] * 6),
-    "df_loss_refine_forward": (_i, [_vp] * 5 + [_i, _i, _i] + [_vp] * 4),
+    "df_loss_forward": (_i, [_vp] * 6 + [_i, _i, _f, _i] + [_vp] * 7),
+    "df_loss_refine_forward": (_i, [_vp] * 5 + [_i, _i, _i] + [_vp] * 5),
+    "df_loss_backward": (_i, [_vp] * 8 + [_i, _i, _f, _f] + [_vp] * 4),
+    "df_loss_refine_backward": (_i, [_vp] * 5 + [_i, _f] + [_vp] * 3),
     "df_add_metric": (_i, [_vp] * 4 + [_i, _i, _vp, _vp]),
     "df_ycb_distances": (_i, [_vp] * 3 + [_i, _i, _vp, _vp, _vp]),
     "df_preprocess_objects": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -52,7 +52,7 @@ __device__ inline float block_sum(float v, float *s_red) {
 __global__ __launch_bounds__(LB) void add_dis_kernel(const float *__restrict__ pred_r, const float *__restrict__ pred_t,
                                                      const float *__restrict__ points, const float *__restrict__ target,
                                                      const float *__restrict__ model, int M, int symmetric,
-                                                     float *__restrict__ dis) {
+                                                     float *__restrict__ dis, int *__restrict__ sel_out) {
   extern __shared__ __attribute__((aligned(16))) float s_tgt[];   // [M][4]
   __shared__ float s_red[LB];
   const int p = blockIdx.x, tid = threadIdx.x;
@@ -85,12 +85,82 @@ __global__ __launch_bounds__(LB) void add_dis_kernel(const float *__restrict__ p
         sel = lt ? r : sel;
       }
     }
+    if (sel_out) sel_out[(size_t)p * M + m] = sel;      // kept for the backward pass (the match is a constant there)
     const float4 q = reinterpret_cast<const float4 *>(s_tgt)[sel];
     const float ex = px - q.x, ey = py - q.y, ez = pz - q.z;
     acc += sqrtf(ex * ex + ey * ey + ez * ez);
   }
   const float tot = block_sum(acc, s_red);
   if (tid == 0) dis[p] = tot / (float)M;
+}
+
+// Backward of dis_p = mean_m || R(q_p/|q_p|) x_m + t_p - tgt_sel(p,m) ||  w.r.t. q_p (un-normalised) and t_p,
+// scaled by an upstream weight wgt[p] (PoseNet loss: g * c_p / N, lib/loss.py:49-50; refiner loss: g).
+// The nearest-neighbour match enters as a constant (torch.index_select on a non-leaf index, lib/loss.py:46).
+// grid = P poses; 12 running sums per thread (sum g, sum g x^T), block-reduced; thread 0 chains through
+// the quaternion -> rotation map (lib/loss.py:18-26) and the normalisation (:16).
+__global__ __launch_bounds__(LB) void add_dis_bwd_kernel(const float *__restrict__ pred_r, const float *__restrict__ pred_t,
+                                                         const float *__restrict__ points, const float *__restrict__ target,
+                                                         const float *__restrict__ model, const int *__restrict__ sel, int M,
+                                                         const float *__restrict__ wgt, float wscale, float *__restrict__ d_r,
+                                                         float *__restrict__ d_t) {
+  __shared__ float s_acc[12][LB];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const Rot R = quat_rot(pred_r + p * 4);
+  float t0 = pred_t[p * 3], t1 = pred_t[p * 3 + 1], t2 = pred_t[p * 3 + 2];
+  if (points) { t0 = points[p * 3] + t0; t1 = points[p * 3 + 1] + t1; t2 = points[p * 3 + 2] + t2; }
+  float a[12];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) a[e] = 0.f;
+  for (int m = tid; m < M; m += LB) {
+    const float x = model[m * 3], y = model[m * 3 + 1], z = model[m * 3 + 2];
+    const float px = (x * R.m[0] + y * R.m[1] + z * R.m[2]) + t0;
+    const float py = (x * R.m[3] + y * R.m[4] + z * R.m[5]) + t1;
+    const float pz = (x * R.m[6] + y * R.m[7] + z * R.m[8]) + t2;
+    const int j = sel ? sel[(size_t)p * M + m] : m;
+    const float ex = px - target[j * 3], ey = py - target[j * 3 + 1], ez = pz - target[j * 3 + 2];
+    const float nrm = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float inv = nrm > 0.f ? 1.f / nrm : 0.f;          // torch.norm's subgradient at 0 is 0
+    const float gx = ex * inv, gy = ey * inv, gz = ez * inv;
+    a[0] += gx; a[1] += gy; a[2] += gz;
+    a[3] += gx * x; a[4] += gx * y; a[5] += gx * z;
+    a[6] += gy * x; a[7] += gy * y; a[8] += gy * z;
+    a[9] += gz * x; a[10] += gz * y; a[11] += gz * z;
+  }
+#pragma unroll
+  for (int e = 0; e < 12; ++e) s_acc[e][tid] = a[e];
+  __syncthreads();
+  for (int d = LB / 2; d >= 1; d >>= 1) {
+    if (tid < d)
+#pragma unroll
+      for (int e = 0; e < 12; ++e) s_acc[e][tid] += s_acc[e][tid + d];
+    __syncthreads();
+  }
+  if (tid != 0) return;
+  const float sc = (wgt ? wgt[p] : 1.f) * wscale / (float)M;
+  float G[9];
+  for (int e = 0; e < 9; ++e) G[e] = s_acc[3 + e][0] * sc;       // dL/dR (row-major)
+  d_t[p * 3 + 0] = s_acc[0][0] * sc; d_t[p * 3 + 1] = s_acc[1][0] * sc; d_t[p * 3 + 2] = s_acc[2][0] * sc;
+  const float *q = pred_r + p * 4;
+  const float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float qa = q[0] / nq, qb = q[1] / nq, qc = q[2] / nq, qd = q[3] / nq;
+  // dL/dq_hat: partial derivatives of the nine entries of lib/loss.py:18-26
+  const float ga = -2.f * qd * G[1] + 2.f * qc * G[2] + 2.f * qd * G[3] - 2.f * qb * G[5] - 2.f * qc * G[6] + 2.f * qb * G[7];
+  const float gb = 2.f * qc * G[1] + 2.f * qd * G[2] + 2.f * qc * G[3] - 4.f * qb * G[4] - 2.f * qa * G[5] + 2.f * qd * G[6] + 2.f * qa * G[7] - 4.f * qb * G[8];
+  const float gc = -4.f * qc * G[0] + 2.f * qb * G[1] + 2.f * qa * G[2] + 2.f * qb * G[3] + 2.f * qd * G[5] - 2.f * qa * G[6] + 2.f * qd * G[7] - 4.f * qc * G[8];
+  const float gd = -4.f * qd * G[0] - 2.f * qa * G[1] + 2.f * qb * G[2] + 2.f * qa * G[3] - 4.f * qd * G[4] + 2.f * qc * G[5] + 2.f * qb * G[6] + 2.f * qc * G[7];
+  // through q_hat = q / |q|:  dq = (g - q_hat (q_hat . g)) / |q|
+  const float dot = qa * ga + qb * gb + qc * gc + qd * gd;
+  d_r[p * 4 + 0] = (ga - qa * dot) / nq;
+  d_r[p * 4 + 1] = (gb - qb * dot) / nq;
+  d_r[p * 4 + 2] = (gc - qc * dot) / nq;
+  d_r[p * 4 + 3] = (gd - qd * dot) / nq;
+}
+
+// PoseNet-loss weights: wgt[n] = c_n (the 1/N and upstream factor go into wscale); d_c[n] = g (dis_n - w/c_n) / N
+__global__ __launch_bounds__(LB) void loss_dc_kernel(const float *__restrict__ pred_c, const float *__restrict__ dis, int N,
+                                                     float w, float g, float *__restrict__ d_c) {
+  for (int n = blockIdx.x * LB + threadIdx.x; n < N; n += gridDim.x * LB) d_c[n] = g * (dis[n] - w / pred_c[n]) / (float)N;
 }
 
 // one workgroup: loss = mean_n(dis*c - w*log c); which = argmax c; dis_sel = dis[which];
@@ -279,7 +349,7 @@ using namespace df;
 extern "C" int df_loss_forward(const float *pred_r, const float *pred_t, const float *pred_c, const float *target,
                                const float *model_points, const float *points, int N, int M, float w, int symmetric,
                                float *loss_out, float *dis_out, float *new_points, float *new_target, float *dis_scratch,
-                               df_stream_t stream) {
+                               int *sel_out, df_stream_t stream) {
   if (!pred_r || !pred_t || !pred_c || !target || !model_points || !points || !loss_out || !dis_out || !new_points ||
       !new_target || !dis_scratch)
     return set_error(DF_ERR_ARG, "loss_forward: null pointer");
@@ -294,7 +364,7 @@ extern "C" int df_loss_forward(const float *pred_r, const float *pred_t, const f
     hipFuncSetAttribute(reinterpret_cast<const void *>(&add_metric_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(add_dis_kernel, dim3(N), dim3(LB), lds, st, pred_r, pred_t, points, target, model_points, M, symmetric, dis_scratch);
+  hipLaunchKernelGGL(add_dis_kernel, dim3(N), dim3(LB), lds, st, pred_r, pred_t, points, target, model_points, M, symmetric, dis_scratch, sel_out);
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(LB), 0, st, pred_r, pred_t, pred_c, points, target, dis_scratch, N, M, w,
                      loss_out, dis_out, new_points, new_target);
   return check_launch("loss_forward");
@@ -302,7 +372,7 @@ extern "C" int df_loss_forward(const float *pred_r, const float *pred_t, const f
 
 extern "C" int df_loss_refine_forward(const float *pred_r, const float *pred_t, const float *target, const float *model_points,
                                       const float *points, int N, int M, int symmetric, float *dis_out, float *new_points,
-                                      float *new_target, df_stream_t stream) {
+                                      float *new_target, int *sel_out, df_stream_t stream) {
   if (!pred_r || !pred_t || !target || !model_points || !points || !dis_out || !new_points || !new_target)
     return set_error(DF_ERR_ARG, "loss_refine_forward: null pointer");
   if (N <= 0) return set_error(DF_ERR_ARG, "loss_refine_forward: N must be >= 1");
@@ -315,7 +385,7 @@ extern "C" int df_loss_refine_forward(const float *pred_r, const float *pred_t, 
     attr = true;
   }
   hipLaunchKernelGGL(add_dis_kernel, dim3(1), dim3(LB), (size_t)M * 16, st, pred_r, pred_t, (const float *)nullptr, target,
-                     model_points, M, symmetric, dis_out);
+                     model_points, M, symmetric, dis_out, sel_out);
   hipLaunchKernelGGL(recentre_kernel, dim3(cdiv(N + M, LB)), dim3(LB), 0, st, pred_r, pred_t, points, target, N, M, new_points, new_target);
   return check_launch("loss_refine_forward");
 }
@@ -346,4 +416,26 @@ extern "C" int df_ycb_distances(const double *rt_est, const double *rt_gt, const
   }
   hipLaunchKernelGGL(ycb_dist_kernel, dim3(B), dim3(LB), (size_t)M * 24, to_stream(stream), rt_est, rt_gt, pts, M, add_out, adi_out);
   return check_launch("ycb_distances");
+}
+
+extern "C" int df_loss_backward(const float *pred_r, const float *pred_t, const float *pred_c, const float *target,
+                                const float *model_points, const float *points, const int *sel, const float *dis, int N, int M,
+                                float w, float g_loss, float *d_pred_r, float *d_pred_t, float *d_pred_c, df_stream_t stream) {
+  if (!pred_r || !pred_t || !pred_c || !target || !model_points || !points || !dis || !d_pred_r || !d_pred_t || !d_pred_c)
+    return set_error(DF_ERR_ARG, "loss_backward: null pointer");
+  if (N <= 0 || M <= 0) return set_error(DF_ERR_ARG, "loss_backward: bad sizes");
+  hipStream_t st = to_stream(stream);
+  hipLaunchKernelGGL(add_dis_bwd_kernel, dim3(N), dim3(LB), 0, st, pred_r, pred_t, points, target, model_points, sel, M, pred_c,
+                     g_loss / (float)N, d_pred_r, d_pred_t);
+  hipLaunchKernelGGL(loss_dc_kernel, dim3(cdiv(N, LB)), dim3(LB), 0, st, pred_c, dis, N, w, g_loss, d_pred_c);
+  return check_launch("loss_backward");
+}
+
+extern "C" int df_loss_refine_backward(const float *pred_r, const float *pred_t, const float *target, const float *model_points,
+                                       const int *sel, int M, float g_dis, float *d_pred_r, float *d_pred_t, df_stream_t stream) {
+  if (!pred_r || !pred_t || !target || !model_points || !d_pred_r || !d_pred_t) return set_error(DF_ERR_ARG, "loss_refine_backward: null pointer");
+  if (M <= 0) return set_error(DF_ERR_ARG, "loss_refine_backward: bad sizes");
+  hipLaunchKernelGGL(add_dis_bwd_kernel, dim3(1), dim3(LB), 0, to_stream(stream), pred_r, pred_t, (const float *)nullptr, target,
+                     model_points, sel, M, (const float *)nullptr, g_dis, d_pred_r, d_pred_t);
+  return check_launch("loss_refine_backward");
 }

@@ -114,10 +114,20 @@ int df_estimate_poses(df_net *posenet, df_net *refiner, int B, int H, int W, con
 int df_loss_forward(const float *pred_r, const float *pred_t, const float *pred_c, const float *target,
                     const float *model_points, const float *points, int N, int M, float w, int symmetric,
                     float *loss_out, float *dis_out, float *new_points, float *new_target, float *dis_scratch,
+                    int *sel_out /* optional [N][M]: matched target index per transformed point, for backward */,
                     df_stream_t stream);
 int df_loss_refine_forward(const float *pred_r, const float *pred_t, const float *target, const float *model_points,
                            const float *points, int N, int M, int symmetric, float *dis_out, float *new_points,
-                           float *new_target, df_stream_t stream);
+                           float *new_target, int *sel_out /* optional [M] */, df_stream_t stream);
+/* Backward of the two losses (what autograd derives from lib/loss.py:16-50 / lib/loss_refiner.py:17-48): gradients
+ * w.r.t. the un-normalised quaternions, the translations and the confidences; the nearest-neighbour match (sel, from
+ * the forward call; NULL = identity) is a constant.  dis = the per-point distances the forward left in dis_scratch.
+ * g_loss / g_dis = upstream gradient of the scalar output (1 for loss.backward()). */
+int df_loss_backward(const float *pred_r, const float *pred_t, const float *pred_c, const float *target,
+                     const float *model_points, const float *points, const int *sel, const float *dis, int N, int M,
+                     float w, float g_loss, float *d_pred_r, float *d_pred_t, float *d_pred_c, df_stream_t stream);
+int df_loss_refine_backward(const float *pred_r, const float *pred_t, const float *target, const float *model_points,
+                            const int *sel, int M, float g_dis, float *d_pred_r, float *d_pred_t, df_stream_t stream);
 int df_add_metric(const double *pose, const float *model_points, const float *target, const int *symmetric, int B,
                   int M, double *dis_out, df_stream_t stream);
 /* YCB-Video toolbox distances (replace_ycb_toolbox/evaluate_poses_keyframe.m:160-193), fp64 like MATLAB:

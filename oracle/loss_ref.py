@@ -29,7 +29,7 @@ def _nearest_target(target_m3: torch.Tensor, pred_pm3: torch.Tensor) -> torch.Te
     """Replace every pred point's target by its nearest target point (lib/loss.py:41-47)."""
     P, M, _ = pred_pm3.shape
     ref = target_m3.t().contiguous().numpy()[None]                      # [1,3,M]
-    qry = pred_pm3.permute(2, 0, 1).contiguous().view(3, -1).numpy()[None]   # [1,3,P*M]
+    qry = pred_pm3.detach().permute(2, 0, 1).contiguous().view(3, -1).numpy()[None]   # [1,3,P*M]; the match is a constant
     inds = torch.from_numpy(knn_ref(ref, qry, 1)[0, 0] - 1)
     return target_m3[inds].view(P, M, 3)
 
@@ -58,7 +58,7 @@ def loss_calculation(pred_r, pred_t, pred_c, target, model_points, idx, points, 
     Rsel = ori_base[which].view(1, 3, 3).contiguous()
     new_points = torch.bmm(pts.view(1, num_p, 3) - t.view(1, 1, 3), Rsel).contiguous()
     new_target = torch.bmm(tg0.view(1, num_point_mesh, 3) - t.view(1, 1, 3), Rsel).contiguous()
-    return loss, dis[which], new_points, new_target
+    return loss, dis[which], new_points.detach(), new_target.detach()      # lib/loss.py:70
 
 
 def loss_refine_calculation(pred_r, pred_t, target, model_points, idx, points, num_point_mesh, sym_list):
@@ -77,4 +77,4 @@ def loss_refine_calculation(pred_r, pred_t, target, model_points, idx, points, n
     dis = torch.mean(torch.norm(pred - tgt, dim=2), dim=1)
     new_points = torch.bmm(points.view(1, n_in, 3) - t, ori_base).contiguous()
     new_target = torch.bmm(tg0.view(1, num_point_mesh, 3) - t, ori_base).contiguous()
-    return dis, new_points, new_target
+    return dis, new_points.detach(), new_target.detach()      # lib/loss_refiner.py:62

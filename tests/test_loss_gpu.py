@@ -93,3 +93,42 @@ def test_loss_argument_errors():
         Loss(500, [])(z(1, 10, 4), z(1, 10, 3), z(1, 10, 1), z(1, 400, 3), z(1, 500, 3), torch.tensor([[0]]).cuda(), z(1, 10, 3), 0.015, False)
     with pytest.raises(RuntimeError):
         Loss(500, [])(torch.zeros(1, 10, 4), z(1, 10, 3), z(1, 10, 1), z(1, 500, 3), z(1, 500, 3), torch.tensor([[0]]), z(1, 10, 3), 0.015, False)
+
+
+@pytest.mark.parametrize("sym", [False, True])
+def test_loss_backward_vs_autograd_of_oracle(sym):
+    """loss.backward() / dis.backward() through the fused kernels == torch autograd through the CPU restatement."""
+    from densefusion_amd.lib.loss import Loss
+    from densefusion_amd.lib.loss_refiner import Loss_refine
+    rng = np.random.Generator(np.random.PCG64(42 + sym))
+    N, M = 120, 90
+    o = synth.make_object(9100, 80, 80, N, 13, num_points_mesh=M)
+    q = rng.standard_normal((1, N, 4)).astype(np.float32)
+    pt = (rng.standard_normal((1, N, 3)) * 0.03).astype(np.float32)
+    pc = rng.uniform(0.05, 0.95, (1, N, 1)).astype(np.float32)
+    tgt, mp, pts = o["target"][None], o["model_points"][None], o["cloud"][None]
+    idx = torch.tensor([[7 if sym else 3]])
+    C = lambda a: torch.from_numpy(a)
+    # CPU: autograd through the oracle
+    cq, ct, cc = C(q).clone().requires_grad_(), C(pt).clone().requires_grad_(), C(pc).clone().requires_grad_()
+    want = loss_ref.loss_calculation(cq, ct, cc, C(tgt), C(mp), idx, C(pts), 0.015, False, M, [7, 8])
+    want[0].backward()
+    # GPU
+    gq, gt, gc = C(q).cuda().requires_grad_(), C(pt).cuda().requires_grad_(), C(pc).cuda().requires_grad_()
+    got = Loss(M, [7, 8])(gq, gt, gc, C(tgt).cuda(), C(mp).cuda(), idx.cuda(), C(pts).cuda(), 0.015, False)
+    assert got[0].requires_grad and not got[2].requires_grad
+    got[0].backward()
+    _close(got[0], want[0], 5e-5)
+    for a, b in ((gq.grad, cq.grad), (gt.grad, ct.grad), (gc.grad, cc.grad)):
+        _close(a, b, 2e-4)
+    # refiner loss
+    q1 = rng.standard_normal((1, 4)).astype(np.float32)
+    t1 = (rng.standard_normal((1, 3)) * 0.02).astype(np.float32)
+    cq1, ct1 = C(q1).clone().requires_grad_(), C(t1).clone().requires_grad_()
+    wr = loss_ref.loss_refine_calculation(cq1, ct1, want[3], C(mp), idx, want[2], M, [7, 8])
+    wr[0].backward()
+    gq1, gt1 = C(q1).cuda().requires_grad_(), C(t1).cuda().requires_grad_()
+    gr = Loss_refine(M, [7, 8])(gq1, gt1, got[3], C(mp).cuda(), idx.cuda(), got[2])
+    gr[0].backward()
+    _close(gr[0], wr[0], 5e-5)
+    _close(gq1.grad, cq1.grad, 2e-4); _close(gt1.grad, ct1.grad, 2e-4)
