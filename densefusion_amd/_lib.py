@@ -48,6 +48,8 @@ SIGNATURES = {
     "df_ycb_distances": (_i, [_vp] * 3 + [_i, _i, _vp, _vp, _vp]),
     "df_preprocess_objects": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "df_conv2d_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp]),
+    "df_conv2d_dgrad_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),
+    "df_conv2d_wgrad_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "df_net_profile": (_i, [_vp, _i]),
     "df_net_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i)]),
 }

@@ -747,6 +747,8 @@ extern "C" int df_estimate_poses(df_net *pn, df_net *rf, int B, int H, int W, co
   return finish(cr, "estimate_poses");
 }
 
+static int conv_desc_to_params(const df_conv_desc *d, ConvParams &p, const char *what);
+
 extern "C" int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream) {
   if (!d) return set_error(DF_ERR_ARG, "conv2d_nhwc: null descriptor");
   if (d->KH != d->KW) return set_error(DF_ERR_ARG, "conv2d_nhwc: square kernels only");
@@ -760,4 +762,68 @@ extern "C" int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream) {
   if (p.OH != conv_out(p.H, p.KH, p.stride, p.pad, p.dil) || p.OW != conv_out(p.W, p.KW, p.stride, p.pad, p.dil))
     return set_error(DF_ERR_ARG, "conv2d_nhwc: OH/OW do not match the convolution geometry");
   return launch_conv(p, to_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// training building blocks: data gradient and weight gradient of df_conv2d_nhwc
+// ------------------------------------------------------------------------------------------------
+namespace df {
+// wt[c][ky][kx][n] = w[n][KH-1-ky][KW-1-kx][c]   (the forward conv's weights as seen by its data gradient)
+__global__ void flip_transpose_kernel(const float *__restrict__ w, float *__restrict__ wt, int O, int T, int I, int KH, int KW) {
+  const long total = (long)O * T * I;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i % O);
+    const long r = i / O;
+    const int t = (int)(r % T);
+    const long c = r / T;
+    const int ky = t / KW, kx = t - ky * KW;
+    const int tf = (KH - 1 - ky) * KW + (KW - 1 - kx);
+    wt[i] = w[((size_t)n * T + tf) * I + c];
+  }
+}
+}  // namespace df
+
+static int conv_desc_to_params(const df_conv_desc *d, ConvParams &p, const char *what) {
+  if (!d) return set_error(DF_ERR_ARG, "%s: null descriptor", what);
+  if (d->KH != d->KW) return set_error(DF_ERR_ARG, "%s: square kernels only", what);
+  p.in = d->in; p.wgt = d->wgt; p.bias = d->bias; p.res = d->res; p.prelu = d->prelu; p.out = d->out;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_ld = d->in_ld; p.in_coff = d->in_coff;
+  p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout; p.out_ld = d->out_ld; p.out_coff = d->out_coff;
+  p.res_ld = d->res_ld; p.res_coff = d->res_coff;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.act = d->act;
+  if (p.OH != conv_out(p.H, p.KH, p.stride, p.pad, p.dil) || p.OW != conv_out(p.W, p.KW, p.stride, p.pad, p.dil))
+    return set_error(DF_ERR_ARG, "%s: OH/OW do not match the convolution geometry", what);
+  return DF_OK;
+}
+
+extern "C" int df_conv2d_dgrad_nhwc(const df_conv_desc *d, const float *dy, float *dx, float *w_scratch, int accumulate,
+                                    df_stream_t stream) {
+  ConvParams f;
+  int rc = conv_desc_to_params(d, f, "conv2d_dgrad");
+  if (rc != DF_OK) return rc;
+  if (!dy || !dx || !w_scratch || !f.wgt) return set_error(DF_ERR_ARG, "conv2d_dgrad: null pointer");
+  if (f.Cout % 4) return set_error(DF_ERR_ARG, "conv2d_dgrad: Cout must be a multiple of 4");
+  hipStream_t st = to_stream(stream);
+  const int T = f.KH * f.KW;
+  hipLaunchKernelGGL(flip_transpose_kernel, dim3(256), dim3(256), 0, st, f.wgt, w_scratch, f.Cout, T, f.Cin, f.KH, f.KW);
+  ConvParams q;
+  q.in = dy; q.B = f.B; q.H = f.OH; q.W = f.OW; q.Cin = f.Cout; q.in_ld = f.out_ld; q.in_coff = f.out_coff;
+  q.wgt = w_scratch;
+  q.out = dx; q.OH = f.H; q.OW = f.W; q.Cout = f.Cin; q.out_ld = f.in_ld; q.out_coff = f.in_coff;
+  q.KH = f.KH; q.KW = f.KW; q.stride = 1; q.up = f.stride; q.dil = f.dil; q.pad = f.dil * (f.KH - 1) - f.pad;
+  if (q.pad < 0) return set_error(DF_ERR_ARG, "conv2d_dgrad: padding larger than the kernel reach is not supported");
+  if (accumulate) { q.res = dx; q.res_ld = f.in_ld; q.res_coff = f.in_coff; }
+  return launch_conv(q, st);
+}
+
+extern "C" int df_conv2d_wgrad_nhwc(const df_conv_desc *d, const float *dy, float *dw, float *db, df_stream_t stream) {
+  ConvParams f;
+  int rc = conv_desc_to_params(d, f, "conv2d_wgrad");
+  if (rc != DF_OK) return rc;
+  if (!dy || !dw || !f.in) return set_error(DF_ERR_ARG, "conv2d_wgrad: null pointer");
+  hipStream_t st = to_stream(stream);
+  f.out = const_cast<float *>(dy);
+  hipMemsetAsync(dw, 0, (size_t)f.Cout * f.KH * f.KW * f.Cin * sizeof(float), st);
+  if (db) hipMemsetAsync(db, 0, (size_t)f.Cout * sizeof(float), st);
+  return launch_wgrad(f, dw, db, st);
 }

@@ -22,6 +22,9 @@ struct ConvParams {
   int OH = 1, OW = 1, Cout = 0, out_ld = 0, out_coff = 0;
   int res_ld = 0, res_coff = 0;
   int KH = 1, KW = 1, stride = 1, pad = 0, dil = 1;
+  // input dilation ("transposed conv" / dgrad of a strided conv): the input is read as if `up`-1 zeros sat between
+  // its pixels: virtual coordinate v = o*stride - pad + k*dil is a real pixel v/up only when v % up == 0
+  int up = 1;
   int act = ACT_NONE;
   // row groups (per-object point blocks): rows_per_group > 0 => row m belongs to group m / rows_per_group
   // and is a real point iff (m % rows_per_group) < rows_valid; used by bias_group_ld and colsum
@@ -38,5 +41,9 @@ double conv_flops(const ConvParams &p);
 // algorithmic HBM bytes (inputs, weights, outputs and residual touched once)
 double conv_bytes(const ConvParams &p);
 int launch_conv(const ConvParams &p, hipStream_t st);
+
+// dW[n][(ky,kx,c)] += sum_m dY[m][n] * A[m][(ky,kx,c)]  (A = the im2col view of x of the forward conv `p`; p.out = dY)
+// dw must be zeroed by the caller; db (optional) += column sums of dY
+int launch_wgrad(const ConvParams &p, float *dw, float *db, hipStream_t st);
 
 }  // namespace df

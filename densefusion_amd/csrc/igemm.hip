@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const ConvParams p) {
 
   // ---- loader state: this thread stages k-vector `vec` of rows lrow + 32*i ----
   const int vec = tid & 7, lrow = tid >> 3;
-  int a_iy0[A_ROWS], a_ix0[A_ROWS], a_pix[A_ROWS];
+  int a_iy0[A_ROWS], a_ix0[A_ROWS], a_pix[A_ROWS];   // a_pix: index of pixel (b, 0, 0)
 #pragma unroll
   for (int i = 0; i < A_ROWS; ++i) {
     const int m = m0 + lrow + 32 * i;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const ConvParams p) {
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
       a_iy0[i] = oy * p.stride - p.pad;
       a_ix0[i] = ox * p.stride - p.pad;
-      a_pix[i] = (b * p.H + a_iy0[i]) * p.W + a_ix0[i];
+      a_pix[i] = b * p.H * p.W;
     } else {
       a_iy0[i] = -(1 << 28);     // fails every bounds check -> zero rows
       a_ix0[i] = 0;
@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const ConvParams p) {
   }
   const bool one_tap = (p.KH * p.KW == 1);
   const int cin_shift = 31 - __builtin_clz(p.Cin);   // multi-tap layers have power-of-two Cin (host-checked)
+  const int up = p.up;
 
   f32x4 ra[A_ROWS], rb[B_ROWS];
   auto load_tile = [&](int kt) {
@@ -100,13 +101,18 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const ConvParams p) {
       dy = ky * p.dil;
       dx = kx * p.dil;
     }
-    const int doff = dy * p.W + dx;
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
-      const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-      const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;          // virtual (input-dilated) coordinates
+      bool ok = kok && iy >= 0 && ix >= 0;
+      if (up > 1) {
+        ok = ok && (iy % up == 0) && (ix % up == 0);
+        iy /= up;
+        ix /= up;
+      }
+      ok = ok && iy < p.H && ix < p.W;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4 *>(in + (size_t)(a_pix[i] + doff) * p.in_ld + c);
+      if (ok) v = *reinterpret_cast<const f32x4 *>(in + (size_t)(a_pix[i] + iy * p.W + ix) * p.in_ld + c);
       ra[i] = v;
     }
 #pragma unroll
@@ -461,6 +467,108 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient: dW[n][k] += sum_m dY[m][n] * A[m][k], k = (ky,kx,c), A = im2col view of the forward input.
+// A GEMM whose reduction runs over the pixels m: both operands are staged [m][channel] (16-B vectors along
+// the contiguous channel axis), the MFMA takes one m pair per step with lanes along n (A operand) and along
+// k (B operand) -- plain ds_read_b32, conflict-free -- and the pixel range is split over blockIdx.z with
+// fp32 atomics combining the partial tiles.  64x64 output tile, 4 waves x one 32x32 accumulator.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(const ConvParams p, float *__restrict__ dw, int m_chunk) {
+  constexpr int TN_ = 64, TK_ = 64, RM = 32, LDS_LD = 68;
+  __shared__ __attribute__((aligned(16))) float sY[2][RM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float sA[2][RM * LDS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = p.B * p.OH * p.OW, K = p.KH * p.KW * p.Cin;
+  const int tiles_k = (K + TK_ - 1) / TK_;
+  const int n0 = (blockIdx.x / tiles_k) * TN_, k0 = (blockIdx.x % tiles_k) * TK_;
+  const int m_begin = blockIdx.z * m_chunk, m_end = min(M, m_begin + m_chunk);
+  const float *__restrict__ x = p.in + p.in_coff;
+  const float *__restrict__ dy = p.out + p.out_coff;
+
+  const int vec = tid & 15, lrow = tid >> 4;           // 16 float4 per 64-wide row, 16 rows per pass
+  // this thread's k vector is fixed for the whole kernel: decode its tap once
+  const int kcol = k0 + vec * 4;
+  const bool kok = kcol < K;
+  int c = kcol, dyy = 0, dxx = 0;
+  if (p.KH * p.KW > 1) {
+    const int tap = kcol / p.Cin;
+    c = kcol - tap * p.Cin;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    dyy = ky * p.dil; dxx = kx * p.dil;
+  }
+  const int ncol = n0 + vec * 4;
+  const bool nok = ncol < p.Cout;
+  const int ohw = p.OH * p.OW;
+
+  f32x4 ry[2], ra[2];
+  auto load_chunk = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mb + lrow + 16 * i;
+      f32x4 vy = {0.f, 0.f, 0.f, 0.f}, va = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end) {
+        if (nok) vy = *reinterpret_cast<const f32x4 *>(dy + (size_t)m * p.out_ld + ncol);
+        const int b = m / ohw, rem = m - b * ohw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        const int iy = oy * p.stride - p.pad + dyy, ix = ox * p.stride - p.pad + dxx;
+        if (kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          va = *reinterpret_cast<const f32x4 *>(x + ((size_t)(b * p.H + iy) * p.W + ix) * p.in_ld + c);
+      }
+      ry[i] = vy; ra[i] = va;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<f32x4 *>(&sY[buf][(lrow + 16 * i) * LDS_LD + vec * 4]) = ry[i];
+      *reinterpret_cast<f32x4 *>(&sA[buf][(lrow + 16 * i) * LDS_LD + vec * 4]) = ra[i];
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nch = (m_end - m_begin + RM - 1) / RM;
+  if (nch > 0) {
+    load_chunk(m_begin);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nch) load_chunk(m_begin + (ch + 1) * RM);
+    const float *py = &sY[buf][lh * LDS_LD + wm * 32 + li];
+    const float *pa = &sA[buf][lh * LDS_LD + wn * 32 + li];
+#pragma unroll
+    for (int kk = 0; kk < RM / 2; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(py[kk * 2 * LDS_LD], pa[kk * 2 * LDS_LD], acc, 0, 0, 0);
+    if (ch + 1 < nch) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int n = n0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, k = k0 + wn * 32 + li;
+    if (n < p.Cout && k < K) atomicAdd(dw + (size_t)n * K + k, acc[e]);
+  }
+}
+
+// db[c] += sum_m dY[m][c]
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float *__restrict__ dy, int M, int C, int ld, int coff,
+                                                        float *__restrict__ db, int rows_per_block) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  __shared__ float s[4][64];
+  float a = 0.f;
+  if (c < C)
+    for (int r = r0 + part; r < r1; r += 4) a += dy[(size_t)r * ld + coff + c];
+  s[part][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (part == 0 && c < C) atomicAdd(db + c, (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]));
+}
+
+
 struct TileCfg { int bm, bn, wmv; };
 
 TileCfg pick_cfg(const ConvParams &p) {
@@ -523,7 +631,7 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
   const bool force_v1 = getenv("DF_IGEMM_V1") != nullptr;   // dev switch: A/B against the un-pipelined kernel
   const size_t in_bytes = ((size_t)p.B * p.H * p.W * p.in_ld + (size_t)(p.zcount - 1) * p.z_in_coff) * sizeof(float);
   const size_t w_bytes = (size_t)p.Cout * p.KH * p.KW * p.Cin * sizeof(float);
-  const bool v2 = !force_v1 && in_bytes < (1ull << 32) && w_bytes < (1ull << 32) && p.Cout % 4 == 0 && p.out_ld % 4 == 0 &&
+  const bool v2 = !force_v1 && p.up == 1 && in_bytes < (1ull << 32) && w_bytes < (1ull << 32) && p.Cout % 4 == 0 && p.out_ld % 4 == 0 &&
                   p.out_coff % 4 == 0 && p.z_out_coff % 4 == 0 && (!p.res || (p.res_ld % 4 == 0 && p.res_coff % 4 == 0)) &&
                   (!p.bias || (p.bias_group_ld % 4 == 0 && p.z_bias % 4 == 0));
   if (v2) {
@@ -548,6 +656,30 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
     hipLaunchKernelGGL((igemm_f32_kernel<64, 64, 2, 2>), grid, dim3(256), lds, st, p);
   }
   return check_launch("igemm");
+}
+
+int launch_wgrad(const ConvParams &p, float *dw, float *db, hipStream_t st) {
+  if (!p.in || !p.out || !dw) return set_error(DF_ERR_ARG, "wgrad: null pointer");
+  if (p.Cin % 4 || p.in_ld % 4 || p.in_coff % 4 || p.out_ld % 4 || p.out_coff % 4 || p.Cout % 4)
+    return set_error(DF_ERR_ARG, "wgrad: channel counts / strides / offsets must be multiples of 4");
+  if (p.up != 1 || p.zcount != 1) return set_error(DF_ERR_ARG, "wgrad: input dilation / grouped launches not supported");
+  const int M = p.B * p.OH * p.OW, K = p.KH * p.KW * p.Cin;
+  if (M <= 0) return DF_OK;
+  const int tiles = ((p.Cout + 63) / 64) * ((K + 63) / 64);
+  // split the pixel range so that ~1024 workgroups are in flight, each with at least 256 pixels
+  int split = (1024 + tiles - 1) / tiles;
+  const int max_split = (M + 255) / 256;
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  const int chunk = ((M + split - 1) / split + 31) / 32 * 32;
+  split = (M + chunk - 1) / chunk;
+  hipLaunchKernelGGL(wgrad_f32_kernel, dim3(tiles, 1, split), dim3(256), 0, st, p, dw, chunk);
+  if (db) {
+    const int rpb = 512;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((p.Cout + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, st, p.out, M, p.Cout, p.out_ld,
+                       p.out_coff, db, rpb);
+  }
+  return check_launch("wgrad");
 }
 
 }  // namespace df

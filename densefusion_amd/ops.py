@@ -33,3 +33,51 @@ def conv2d_nhwc(x, w, bias=None, stride=1, pad=0, dil=1, act=0, res=None, prelu=
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().df_conv2d_nhwc(ctypes.byref(d), _lib.current_stream()), "conv2d_nhwc")
     return out
+
+
+def _desc(x, w, out, stride, pad, dil, act=0, bias=None):
+    B, H, W, in_ld = x.shape
+    Cout, KH, KW, Cin = w.shape
+    d = _lib.ConvDesc()
+    d.in_, d.wgt, d.out = _lib.dptr(x), _lib.dptr(w), (_lib.dptr(out) if out is not None else None)
+    d.bias = _lib.dptr(bias) if bias is not None else None
+    d.B, d.H, d.W, d.Cin, d.in_ld, d.in_coff = B, H, W, Cin, in_ld, 0
+    d.OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    d.OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    d.Cout, d.out_ld, d.out_coff = Cout, Cout, 0
+    d.KH, d.KW, d.stride, d.pad, d.dil, d.act = KH, KW, stride, pad, dil, act
+    return d
+
+
+class ConvNHWC(torch.autograd.Function):
+    """y = conv(x [B,H,W,Cin], w [Cout,KH,KW,Cin]) + bias on the fp32-MFMA kernels, with native data and
+    weight gradients (df_conv2d_dgrad_nhwc / df_conv2d_wgrad_nhwc).  The activation is left to the caller."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, dil):
+        x, w = x.contiguous(), w.contiguous()
+        y = conv2d_nhwc(x, w, bias, stride=stride, pad=pad, dil=dil)
+        ctx.save_for_backward(x, w)
+        ctx.geom = (stride, pad, dil, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, dil, has_bias = ctx.geom
+        dy = dy.contiguous()
+        L = _lib.lib()
+        d = _desc(x, w, None, stride, pad, dil)
+        dx = dw = db = None
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                scratch = torch.empty_like(w)
+                _lib.check(L.df_conv2d_dgrad_nhwc(ctypes.byref(d), dy.data_ptr(), dx.data_ptr(), scratch.data_ptr(), 0,
+                                                  _lib.current_stream()), "conv2d_dgrad")
+            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+                dw = torch.empty_like(w)
+                db = torch.empty(w.shape[0], device=x.device) if has_bias else None
+                _lib.check(L.df_conv2d_wgrad_nhwc(ctypes.byref(d), dy.data_ptr(), dw.data_ptr(),
+                                                  db.data_ptr() if db is not None else None, _lib.current_stream()), "conv2d_wgrad")
+        return dx, dw, db, None, None, None

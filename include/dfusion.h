@@ -169,6 +169,15 @@ typedef struct df_conv_desc {
   int32_t KH, KW, stride, pad, dil, act;
 } df_conv_desc;
 int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream);
+/* Gradients of df_conv2d_nhwc (training path; `d` describes the FORWARD convolution, d->wgt = its weights):
+ *   dgrad: dx[b][iy][ix][in_coff + c] (+)= sum dy[b][oy][ox][out_coff + n] * wgt[n][ky][kx][c] over the taps/outputs that
+ *          read that input pixel; runs on the same MFMA kernel as the forward pass on flipped, transposed weights
+ *          (w_scratch: Cout*KH*KW*Cin floats) with input dilation = the forward stride.  accumulate != 0 adds into dx.
+ *   wgrad: dw[n][ky][kx][c] = sum_pixels dy[.][n] * x[. shifted by tap][c];  db[n] = sum_pixels dy[.][n] (db may be NULL).
+ * dy has the geometry of the forward output (out_ld / out_coff of `d`); activation masks are the caller's business. */
+int df_conv2d_dgrad_nhwc(const df_conv_desc *d, const float *dy, float *dx, float *w_scratch, int accumulate,
+                         df_stream_t stream);
+int df_conv2d_wgrad_nhwc(const df_conv_desc *d, const float *dy, float *dw, float *db, df_stream_t stream);
 
 /* Per-launch timing of the GEMM kernel with HIP events on the call's stream (bench.py roofline).
  * df_net_profile(net, 1) arms it; after the stream has been synchronised df_net_profile_read returns the
