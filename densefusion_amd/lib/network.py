@@ -11,8 +11,9 @@ What is different: there is no module tree of nn.Conv layers -- parameters are p
 pointers to the C ABI (include/dfusion.h).  The reference evaluates batch element 0 only
 (``b = 0``, network.py:123,202); here a leading batch of B same-sized objects is evaluated
 independently and all B results are returned (B = 1 reproduces the reference shapes).
-Inference only for now: ``forward`` in ``train()`` mode raises (Dropout2d + backward kernels are
-not part of this round).
+``eval()`` mode runs the fused inference engine; ``train()`` mode runs the differentiable
+layer-by-layer path of ``train_graph`` (convolution / GEMM forward, data- and weight-gradients on the MFMA
+kernels, autograd as the tape, Dropout2d active), one object per call like the reference.
 """
 from __future__ import annotations
 
@@ -101,8 +102,7 @@ class _EngineModule(nn.Module):
 
     def _check_mode(self):
         if self.training:
-            raise RuntimeError(f"{type(self).__name__}: only eval() mode is implemented on the HIP path "
-                               "(call .eval(); the training path is not part of this round)")
+            raise RuntimeError(f"{type(self).__name__}: this entry point is inference-only; call .eval() first")
 
 
 def _dev_f32(t, device=None):
@@ -117,8 +117,15 @@ class PoseNet(_EngineModule):
 
     def forward(self, img, x, choose, obj):
         """img [B,3,H,W], x [B,N,3], choose [B,1,N]|[B,N] int64, obj [B,1]|[B] int64 ->
-        (out_rx [B,N,4], out_tx [B,N,3], out_cx [B,N,1], emb [B,32,N])   (lib/network.py:95-132)."""
-        self._check_mode()
+        (out_rx [B,N,4], out_tx [B,N,3], out_cx [B,N,1], emb [B,32,N])   (lib/network.py:95-132).
+
+        In ``train()`` mode (or when gradients are required) the differentiable layer-by-layer path of
+        ``train_graph`` runs instead of the fused inference engine: bs = 1, Dropout2d active, autograd graph built."""
+        if self.training:
+            from . import train_graph
+            if img.shape[0] != 1:
+                raise RuntimeError("PoseNet.forward in train() mode evaluates one object per call (bs = 1, like the reference)")
+            return train_graph.posenet_forward(self, img.float(), x.float(), choose, obj, dropout=True)
         img, x = _dev_f32(img), _dev_f32(x)
         dev = img.device
         B, C, H, W = img.shape
@@ -150,8 +157,13 @@ class PoseRefineNet(_EngineModule):
     _kind = "refiner"
 
     def forward(self, x, emb, obj):
-        """x [B,N,3], emb [B,32,N], obj [B,1]|[B] -> (out_rx [B,4], out_tx [B,3])   (lib/network.py:187-206)."""
-        self._check_mode()
+        """x [B,N,3], emb [B,32,N], obj [B,1]|[B] -> (out_rx [B,4], out_tx [B,3])   (lib/network.py:187-206).
+        ``train()`` mode: differentiable path (``train_graph.refiner_forward``), bs = 1."""
+        if self.training:
+            from . import train_graph
+            if x.shape[0] != 1:
+                raise RuntimeError("PoseRefineNet.forward in train() mode evaluates one object per call (bs = 1)")
+            return train_graph.refiner_forward(self, x.float(), emb.float(), obj)
         x, emb = _dev_f32(x), _dev_f32(emb)
         dev = x.device
         B, N = x.shape[0], self.num_points
