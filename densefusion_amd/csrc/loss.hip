@@ -439,3 +439,36 @@ extern "C" int df_loss_refine_backward(const float *pred_r, const float *pred_t,
                      model_points, sel, M, (const float *)nullptr, g_dis, d_pred_r, d_pred_t);
   return check_launch("loss_refine_backward");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Adam step on a flat fp32 buffer (what optim.Adam does per tensor in tools/train.py:99,166-169: default
+// betas/eps, no weight decay, no amsgrad); grad_scale folds the 1/(world*accumulated) averaging of the
+// data-parallel all-reduce into the same pass.
+// ------------------------------------------------------------------------------------------------
+namespace df {
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2_sqrt, float grad_scale) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i] * grad_scale;
+    const float mi = m[i] + (1.f - b1) * (gi - m[i]);             // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+  }
+}
+}  // namespace df
+
+extern "C" int df_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                            float beta2, float eps, int step, float grad_scale, df_stream_t stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq) return set_error(DF_ERR_ARG, "adam_step: null pointer");
+  if (n < 0 || step < 1) return set_error(DF_ERR_ARG, "adam_step: need n >= 0 and step >= 1");
+  if (n == 0) return DF_OK;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, to_stream(stream), param, grad, exp_avg, exp_avg_sq, (long)n,
+                     lr, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
+  return check_launch("adam_step");
+}

@@ -136,6 +136,12 @@ int df_add_metric(const double *pose, const float *model_points, const float *ta
 int df_ycb_distances(const double *rt_est, const double *rt_gt, const double *pts, int B, int M, double *add_out,
                      double *adi_out, df_stream_t stream);
 
+/* Adam update of a flat fp32 parameter buffer (the optimizer of tools/train.py:99 with its default betas / eps):
+ *   m = m + (1-b1)(g' - m);  v = b2 v + (1-b2) g'^2;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps),  g' = grad_scale * g
+ * grad_scale carries the 1/(ranks x accumulated samples) of the data-parallel gradient average. */
+int df_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int step, float grad_scale, df_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Input preparation on the device (the numpy block of tools/eval_ycb.py:147-181, per detected object):
  * mask = (depth != 0) & (label == itemid) inside the snapped box; choose = num_points mask pixels (random

@@ -1,0 +1,252 @@
+#!/usr/bin/env python
+"""Two-phase DenseFusion trainer on the HIP path -- the job of the reference's tools/train.py:51-251.
+
+Phase A trains PoseNet with the confidence-weighted ADD(-S) loss until the test distance drops below
+``--refine_margin``; phase B freezes it and trains PoseRefineNet for ``--iteration`` refinement steps per frame.
+One frame per forward/backward (bs = 1, like the reference), ``--batch_size`` frames accumulated per optimizer
+step, Adam, per-epoch test pass, ``*_current.pth`` every 1000 frames and best-model checkpoints with the
+reference's file names, so its eval scripts and ours load them.
+
+Data-parallel over the GPUs of one node (one process per GPU, ``torch.distributed`` backend "nccl" = RCCL over
+xGMI): every rank trains on its own shard of the frame list, gradients live in ONE flat fp32 buffer
+(85.8 MB for PoseNet, 7.8 MB for the refiner) that is summed with ONE all-reduce per optimizer step; nothing
+else is communicated.  Launch: ``python -m torch.distributed.run --nproc-per-node N tools/train.py ...``.
+
+``--dataset synthetic`` trains on seeded synthetic frames (no dataset ships offline); ``ycb`` / ``linemod`` import
+``datasets.<name>.dataset.PoseDataset`` from the PYTHONPATH (the reference's loaders work unchanged: they return
+the 6-tuple cloud, choose, img, target, model_points, idx).
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from densefusion_amd import synth, train_utils  # noqa: E402
+from densefusion_amd.lib.loss import Loss  # noqa: E402
+from densefusion_amd.lib.loss_refiner import Loss_refine  # noqa: E402
+from densefusion_amd.lib.network import PoseNet, PoseRefineNet  # noqa: E402
+
+
+class SyntheticPoseDataset(torch.utils.data.Dataset):
+    """Seeded synthetic frames in the reference's dataset tuple layout (datasets/ycb/dataset.py:227-232)."""
+    CROPS = [(80, 80), (120, 120), (120, 160), (160, 160)]
+
+    def __init__(self, mode, num_pt, num_obj, length, num_pt_mesh=500, sym=(12, 15, 18, 19, 20), crops=None, seed=0):
+        self.mode, self.num_pt, self.num_obj, self.length = mode, num_pt, num_obj, length
+        self.num_pt_mesh, self.sym = num_pt_mesh, [s for s in sym if s < num_obj]
+        self.crops = crops or self.CROPS
+        self.seed = seed + (0 if mode == "train" else 10_000_000)
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        H, W = self.crops[i % len(self.crops)]
+        o = synth.make_object(self.seed + i, H, W, self.num_pt, self.num_obj, self.num_pt_mesh)
+        return (torch.from_numpy(o["cloud"]), torch.from_numpy(o["choose"]), torch.from_numpy(o["img"]),
+                torch.from_numpy(o["target"]), torch.from_numpy(o["model_points"]), torch.from_numpy(o["obj"]))
+
+    def get_sym_list(self):
+        return self.sym
+
+    def get_num_points_mesh(self):
+        return self.num_pt_mesh
+
+
+def build_parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dataset", type=str, default="synthetic", help="synthetic | ycb | linemod")
+    ap.add_argument("--dataset_root", type=str, default="")
+    ap.add_argument("--batch_size", type=int, default=8, help="frames accumulated per optimizer step and GPU")
+    ap.add_argument("--workers", type=int, default=4)
+    ap.add_argument("--lr", type=float, default=0.0001)
+    ap.add_argument("--lr_rate", type=float, default=0.3)
+    ap.add_argument("--w", type=float, default=0.015)
+    ap.add_argument("--w_rate", type=float, default=0.3)
+    ap.add_argument("--decay_margin", type=float, default=0.016)
+    ap.add_argument("--refine_margin", type=float, default=0.013)
+    ap.add_argument("--noise_trans", type=float, default=0.03)
+    ap.add_argument("--iteration", type=int, default=2)
+    ap.add_argument("--nepoch", type=int, default=500)
+    ap.add_argument("--resume_posenet", type=str, default="")
+    ap.add_argument("--resume_refinenet", type=str, default="")
+    ap.add_argument("--start_epoch", type=int, default=1)
+    ap.add_argument("--outf", type=str, default="trained_models/synthetic")
+    ap.add_argument("--log_dir", type=str, default="experiments/logs/synthetic")
+    # synthetic-data knobs
+    ap.add_argument("--num_objects", type=int, default=21)
+    ap.add_argument("--num_points", type=int, default=1000)
+    ap.add_argument("--synthetic_train_frames", type=int, default=64)
+    ap.add_argument("--synthetic_test_frames", type=int, default=16)
+    ap.add_argument("--refine_start", action="store_true")
+    return ap
+
+
+def make_datasets(opt):
+    if opt.dataset == "synthetic":
+        tr = SyntheticPoseDataset("train", opt.num_points, opt.num_objects, opt.synthetic_train_frames)
+        te = SyntheticPoseDataset("test", opt.num_points, opt.num_objects, opt.synthetic_test_frames)
+        return tr, te
+    if opt.dataset == "ycb":
+        from datasets.ycb.dataset import PoseDataset
+        opt.num_objects, opt.num_points = 21, 1000
+    elif opt.dataset == "linemod":
+        from datasets.linemod.dataset import PoseDataset
+        opt.num_objects, opt.num_points = 13, 500
+    else:
+        raise SystemExit("Unknown dataset")
+    return (PoseDataset("train", opt.num_points, True, opt.dataset_root, opt.noise_trans, opt.refine_start),
+            PoseDataset("test", opt.num_points, False, opt.dataset_root, 0.0, opt.refine_start))
+
+
+def main(argv=None):
+    opt = build_parser().parse_args(argv)
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(1000 + rank)
+    np.random.seed(1000 + rank)
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format="%(message)s")
+    log = logging.getLogger("train")
+    os.makedirs(opt.outf, exist_ok=True)
+    os.makedirs(opt.log_dir, exist_ok=True)
+
+    dataset, test_dataset = make_datasets(opt)
+    estimator = PoseNet(num_points=opt.num_points, num_obj=opt.num_objects).to(dev)
+    refiner = PoseRefineNet(num_points=opt.num_points, num_obj=opt.num_objects).to(dev)
+    if opt.resume_posenet:
+        estimator.load_state_dict(torch.load(os.path.join(opt.outf, opt.resume_posenet), map_location=dev, weights_only=True))
+    if opt.resume_refinenet:
+        refiner.load_state_dict(torch.load(os.path.join(opt.outf, opt.resume_refinenet), map_location=dev, weights_only=True))
+        opt.refine_start = True
+        opt.lr *= opt.lr_rate
+        opt.w *= opt.w_rate
+        opt.batch_size = max(1, int(opt.batch_size / opt.iteration))
+    decay_start = False
+
+    def optimizer_for(module):
+        flat = train_utils.FlatParams(module)
+        return flat, train_utils.FlatAdam(flat, lr=opt.lr)
+
+    flat, optimizer = optimizer_for(refiner if opt.refine_start else estimator)
+    opt.sym_list = dataset.get_sym_list()
+    opt.num_points_mesh = dataset.get_num_points_mesh()
+    criterion = Loss(opt.num_points_mesh, opt.sym_list)
+    criterion_refine = Loss_refine(opt.num_points_mesh, opt.sym_list)
+    log.info(">>>>>>>>----------Dataset loaded!---------<<<<<<<<\nlength of the training set: %d\nlength of the testing set: %d\n"
+             "number of sample points on mesh: %d\nsymmetry object list: %s", len(dataset), len(test_dataset), opt.num_points_mesh, opt.sym_list)
+
+    def to_dev(data):
+        points, choose, img, target, model_points, idx = data
+        if points.dim() == 2:                       # the LineMOD loader's "lost detection" sentinel
+            return None
+        f = lambda t: t.to(dev)[None]                # add the bs = 1 axis the DataLoader of the reference adds
+        return f(points), choose.to(dev).reshape(1, 1, -1), f(img), f(target), f(model_points), idx.to(dev).reshape(1, 1)
+
+    best_test = np.inf
+    st_time = time.time()
+    frames_seen = 0
+    for epoch in range(opt.start_epoch, opt.nepoch):
+        if opt.refine_start:
+            estimator.eval(); refiner.train()
+        else:
+            estimator.train()
+        flat.zero_grad()
+        train_count, train_dis_avg = 0, 0.0
+        order = np.random.permutation(len(dataset))[rank::world]       # this rank's shard of the epoch
+        for i in order:
+            data = to_dev(dataset[int(i)])
+            if data is None:
+                continue
+            points, choose, img, target, model_points, idx = data
+            if opt.refine_start:
+                with torch.no_grad():
+                    pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx)
+                    _, dis, new_points, new_target = criterion(pred_r, pred_t, pred_c, target, model_points, idx, points, opt.w, True)
+                for _ in range(opt.iteration):
+                    pred_r, pred_t = refiner(new_points, emb, idx)
+                    dis, new_points, new_target = criterion_refine(pred_r, pred_t, new_target, model_points, idx, new_points)
+                    dis.backward()
+            else:
+                pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx)
+                loss, dis, new_points, new_target = criterion(pred_r, pred_t, pred_c, target, model_points, idx, points, opt.w, False)
+                loss.backward()
+            train_dis_avg += float(dis)
+            train_count += 1
+            frames_seen += 1
+            if train_count % opt.batch_size == 0:
+                n = train_utils.allreduce_gradients(flat)             # the one collective of the training path
+                optimizer.step(grad_scale=1.0 / n)
+                flat.zero_grad()
+                log.info("Train time %s Epoch %d Batch %d Frame %d Avg_dis:%f", time.strftime("%Hh %Mm %Ss", time.gmtime(time.time() - st_time)),
+                         epoch, train_count // opt.batch_size, train_count, train_dis_avg / opt.batch_size)
+                train_dis_avg = 0.0
+            if train_count % 1000 == 0 and rank == 0:
+                if opt.refine_start:
+                    torch.save(refiner.state_dict(), "{0}/pose_refine_model_current.pth".format(opt.outf))
+                else:
+                    torch.save(estimator.state_dict(), "{0}/pose_model_current.pth".format(opt.outf))
+        log.info(">>>>>>>>----------epoch %d train finish---------<<<<<<<<", epoch)
+
+        # per-epoch test pass (tools/train.py:181-209): the fused inference engine, no gradients
+        estimator.eval(); refiner.eval()
+        test_dis, test_count = 0.0, 0
+        with torch.no_grad():
+            for j in range(rank, len(test_dataset), world):
+                data = to_dev(test_dataset[j])
+                if data is None:
+                    continue
+                points, choose, img, target, model_points, idx = data
+                pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx)
+                _, dis, new_points, new_target = criterion(pred_r, pred_t, pred_c, target, model_points, idx, points, opt.w, opt.refine_start)
+                if opt.refine_start:
+                    for _ in range(opt.iteration):
+                        pred_r, pred_t = refiner(new_points, emb, idx)
+                        dis, new_points, new_target = criterion_refine(pred_r, pred_t, new_target, model_points, idx, new_points)
+                test_dis += float(dis)
+                test_count += 1
+        stats = torch.tensor([test_dis, float(test_count)], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(stats)
+        test_dis = float(stats[0] / max(stats[1], 1.0))
+        log.info("Test time %s Epoch %d TEST FINISH Avg dis: %f", time.strftime("%Hh %Mm %Ss", time.gmtime(time.time() - st_time)), epoch, test_dis)
+        if test_dis <= best_test:
+            best_test = test_dis
+            if rank == 0:
+                if opt.refine_start:
+                    torch.save(refiner.state_dict(), "{0}/pose_refine_model_{1}_{2}.pth".format(opt.outf, epoch, test_dis))
+                else:
+                    torch.save(estimator.state_dict(), "{0}/pose_model_{1}_{2}.pth".format(opt.outf, epoch, test_dis))
+                log.info("%d >>>>>>>>----------BEST TEST MODEL SAVED---------<<<<<<<<", epoch)
+        if best_test < opt.decay_margin and not decay_start:
+            decay_start = True
+            opt.lr *= opt.lr_rate
+            opt.w *= opt.w_rate
+            optimizer = train_utils.FlatAdam(flat, lr=opt.lr)
+        if best_test < opt.refine_margin and not opt.refine_start:
+            opt.refine_start = True
+            opt.batch_size = max(1, int(opt.batch_size / opt.iteration))
+            flat, optimizer = optimizer_for(refiner)
+            if opt.dataset != "synthetic":
+                dataset, test_dataset = make_datasets(opt)
+                opt.sym_list, opt.num_points_mesh = dataset.get_sym_list(), dataset.get_num_points_mesh()
+                criterion, criterion_refine = Loss(opt.num_points_mesh, opt.sym_list), Loss_refine(opt.num_points_mesh, opt.sym_list)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return best_test
+
+
+if __name__ == "__main__":
+    main()
