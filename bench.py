@@ -140,7 +140,24 @@ def bench_knn():
     us = e0.elapsed_time(e1) / n * 1e3
     byts, flops = 12 * (R + Q) + 8 * Q, 9.0 * R * Q
     gbs, tfl = byts / us / 1e3, flops / us / 1e6
-    return {"kernel": "knn1_dim3_kernel", "R": R, "Q": Q, "us_per_launch": round(us, 2),
+    # BASELINE configs[4]: KNN stress, num_points = 2000 -> R = 500, Q = 1 000 000, 64 independent problems per GPU
+    Bs, Qs = 64, 1000000
+    refs = (torch.rand(Bs, 3, R, device="cuda") - 0.5) * 0.2
+    qrys = (torch.rand(Bs, 3, Qs, device="cuda") - 0.5) * 0.25
+    knn(refs, qrys)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(3):
+        knn(refs, qrys)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_s = e0.elapsed_time(e1) / 3
+    stress = {"batch": Bs, "R": R, "Q": Qs, "ms_per_launch": round(ms_s, 3), "Gpairs_per_s": round(Bs * R * Qs / ms_s / 1e6, 1),
+              "achieved_GBps": round(Bs * (12 * (R + Qs) + 8 * Qs) / ms_s / 1e6, 1),
+              "achieved_TFLOPs": round(9.0 * Bs * R * Qs / ms_s / 1e9, 2),
+              "fp32_valu_frac": round(9.0 * Bs * R * Qs / ms_s / 1e9 / FP32_PEAK_TFLOPS, 4)}
+    del refs, qrys
+    return {"kernel": "knn1_dim3_kernel", "R": R, "Q": Q, "us_per_launch": round(us, 2), "stress_config5": stress,
             "algorithmic_bytes": byts, "achieved_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
             "algorithmic_flops": flops, "achieved_TFLOPs": round(tfl, 2), "fp32_valu_frac": round(tfl / FP32_PEAK_TFLOPS, 4),
             "bound": "fp32-valu (arithmetic intensity 9R/20 = 225 FLOP/B >> ridge ~20)"}

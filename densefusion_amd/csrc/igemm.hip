@@ -577,6 +577,9 @@ TileCfg pick_cfg(const ConvParams &p) {
   // 128-padded groups the engine uses.)  Pick the tile that minimises  ceil(tiles / 256 CUs) * tile_area / efficiency : the chip
   // finishes when its most loaded CU does, so a 128x128 grid of e.g. 800 tiles (4 rounds for 3.1 rounds
   // of work) loses to the same problem cut into 3200 64x64 tiles (13 rounds for 12.5).
+  // The fused column sum adds rows in per-wave groups: keep that grouping independent of the batch size (so
+  // a batched call stays bit-identical to solo calls) by always using the 128x128 tile for it.
+  if (p.colsum || !p.out) return {128, 128, 2};     // (!p.out: the same launch while its partial buffer is being sized)
   auto cost = [&](int bm, int bn, double eff) {
     const long tiles = ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * p.zcount;
     const long rounds = (tiles + 255) / 256;

@@ -132,3 +132,56 @@ def test_state_dict_contract_and_errors():
     with pytest.raises(RuntimeError):                                       # wrong point count
         est(torch.zeros(1, 3, 80, 80).cuda(), torch.zeros(1, 400, 3).cuda(), torch.zeros(1, 1, 400, dtype=torch.long).cuda(),
             torch.zeros(1, 1, dtype=torch.long).cuda())
+
+
+def test_stress_shapes_num_points_2000_and_wide_batch():
+    """BASELINE configs[4] shape (num_points = 2000) and a wide batch through the same engine: results must
+    still agree with the CPU oracle, and a batch of 24 must equal 24 solo runs bit for bit."""
+    from densefusion_amd.lib.network import PoseEstimator
+    K, N, H, W = 21, 2000, 80, 120
+    est, ref = _nets(K, N, 17)
+    pe = PoseEstimator(est, ref)
+    b = synth.make_batch(91, 2, H, W, N, K)
+    T = lambda k: torch.from_numpy(b[k]).cuda()
+    wo, pose = pe.estimate(T("img"), T("cloud"), T("choose"), T("obj"), 2)
+    sdp = dfnet._to_torch_sd(synth.make_state_dict(synth.posenet_spec(K), 17))
+    sdr = dfnet._to_torch_sd(synth.make_state_dict(synth.refiner_spec(K), 1017))
+    for i in range(2):
+        args = tuple(torch.from_numpy(b[k][i:i + 1]) for k in ("img", "cloud", "choose", "obj"))
+        with torch.no_grad():
+            o_c = dfnet.posenet_forward(sdp, *args)[2]
+            cs = torch.sort(o_c.view(-1))[0]
+            owo, opose = pose_math.estimate_pose(sdp, sdr, *args, 2)
+        if float(cs[-1] - cs[-2]) > 1e-4:
+            assert _add(pose[i].cpu().numpy(), opose, b["model_points"][i]) < ADD_TOL
+    K, N, H, W, B = 13, 500, 80, 80, 24
+    est, ref = _nets(K, N, 12)
+    pe = PoseEstimator(est, ref)
+    b = synth.make_batch(92, B, H, W, N, K, cam=synth.LINEMOD_CAM)
+    T = lambda k: torch.from_numpy(b[k]).cuda()
+    wo, pose = pe.estimate(T("img"), T("cloud"), T("choose"), T("obj"), 4)
+    for i in (0, 7, 23):
+        sl = lambda k: torch.from_numpy(b[k][i:i + 1]).cuda()
+        _, p1 = pe.estimate(sl("img"), sl("cloud"), sl("choose"), sl("obj"), 4)
+        assert torch.equal(p1[0], pose[i])
+
+
+@pytest.mark.parametrize("poison", [float("nan"), 1e30])
+def test_results_do_not_depend_on_workspace_garbage(poison):
+    """The engine computes (and ignores) padded point rows and unused pyramid rows; nothing a caller sees may
+    depend on what the scratch memory held before: poison the workspace and require bit-identical outputs."""
+    from densefusion_amd.lib.network import PoseEstimator
+    K, N, H, W = 21, 1000, 80, 120
+    est, ref = _nets(K, N, 13)
+    pe = PoseEstimator(est, ref)
+    b = synth.make_batch(55, 2, H, W, N, K)
+    T = lambda k: torch.from_numpy(b[k]).cuda()
+    r0 = est(T("img"), T("cloud"), T("choose"), T("obj"))
+    p0 = pe.estimate(T("img"), T("cloud"), T("choose"), T("obj"), 2)
+    p0 = (p0[0].clone(), p0[1].clone())
+    est._ws.view(torch.float32).fill_(poison)
+    pe._ws.view(torch.float32).fill_(poison)
+    r1 = est(T("img"), T("cloud"), T("choose"), T("obj"))
+    p1 = pe.estimate(T("img"), T("cloud"), T("choose"), T("obj"), 2)
+    for a, c in zip(r0 + p0, r1 + p1):
+        assert torch.equal(a, c)
