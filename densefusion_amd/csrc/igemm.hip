@@ -390,9 +390,9 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
 #pragma unroll
         for (int q = 0; q < 8 * TM * TN; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, TM * TN == 4 ? 3 : 8, 0);     // VALU
-          __builtin_amdgcn_sched_group_barrier(0x004, TM * TN == 4 ? 1 : 3, 0);     // SALU
-          __builtin_amdgcn_sched_group_barrier(0x090, TM * TN == 4 ? 1 : 2, 0);     // DS | VMEM
+          __builtin_amdgcn_sched_group_barrier(0x002, TM * TN == 4 ? 3 : (TM * TN == 2 ? 5 : 8), 0);     // VALU
+          __builtin_amdgcn_sched_group_barrier(0x004, TM * TN == 4 ? 1 : (TM * TN == 2 ? 2 : 3), 0);     // SALU
+          __builtin_amdgcn_sched_group_barrier(0x090, TM * TN == 4 ? 1 : 2, 0);                          // DS | VMEM
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float *__restrict_
 }
 
 
-struct TileCfg { int bm, bn, wmv; };
+struct TileCfg { int bm, bn, wmv; };     // workgroup tile and waves along M
 
 TileCfg pick_cfg(const ConvParams &p) {
   const long M = (long)p.B * p.OH * p.OW;
@@ -585,7 +585,12 @@ TileCfg pick_cfg(const ConvParams &p) {
     const long rounds = (tiles + 255) / 256;
     return (double)rounds * bm * bn / eff;
   };
-  const double c128 = cost(128, 128, 1.0), c64 = cost(64, 64, 0.94);
+  if (const char *t = getenv("DF_IGEMM_TILE")) {      // dev switch for A/B runs (tools/gemm_ab.py)
+    if (t[0] == 'a') return {128, 128, 2};
+    if (t[0] == 'c') return {64, 64, 2};
+  }
+  // (a 128x64 tile was measured too: never better than 64x64, up to 1.8x worse on small grids)
+  const double c128 = cost(128, 128, 1.0), c64 = cost(64, 64, 0.96);
   if (p.Cout >= 128 && c128 <= c64) return {128, 128, 2};
   return {64, 64, 2};
 }
@@ -647,13 +652,13 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
       attr2 = true;
     }
     const bool bk32 = getenv("DF_IGEMM_BK64") == nullptr;      // dev switch: BK=64 measured slower on most 64x64 shapes
-    if (c.bm == 128)
+    if (c.bm == 128 && c.bn == 128)
       hipLaunchKernelGGL((igemm_f32_v2_kernel<128, 128, 2, 2, 32>), grid, dim3(256), (size_t)2 * 256 * 36 * sizeof(float), st, p);
     else if (bk32)
       hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2, 32>), grid, dim3(256), (size_t)2 * 128 * 36 * sizeof(float), st, p);
     else
       hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2, 64>), grid, dim3(256), (size_t)2 * 128 * 68 * sizeof(float), st, p);
-  } else if (c.bm == 128) {
+  } else if (c.bm == 128 && c.bn == 128) {
     hipLaunchKernelGGL((igemm_f32_kernel<128, 128, 2, 2>), grid, dim3(256), lds, st, p);
   } else {
     hipLaunchKernelGGL((igemm_f32_kernel<64, 64, 2, 2>), grid, dim3(256), lds, st, p);
