@@ -222,30 +222,42 @@ def main():
     ap.add_argument("--no-streams", action="store_true", help="run the crop-size buckets back to back on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse "
+                                                      "the multi-rank path with several ranks on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "DF_BENCH_DEVICE" in os.environ:            # rehearsal only: several ranks sharing one card
+        local = int(os.environ["DF_BENCH_DEVICE"])
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+        if args.backend == "nccl":                  # "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     est, ref = load_nets(device)
     buckets = make_buckets(rank, world, args.per_bucket, device)
     pe = [PoseEstimator(est, ref) for _ in buckets]         # one workspace per bucket (they may run concurrently)
     streams = None if args.no_streams else [torch.cuda.Stream() for _ in buckets]
     poses_per_step = args.per_bucket * len(CROPS)
-    gathered = [torch.empty(poses_per_step, 7, dtype=torch.float64, device=device) for _ in range(world)] if world > 1 else None
+    gdev = device if args.backend == "nccl" else torch.device("cpu")
+    gathered = [torch.empty(poses_per_step, 7, dtype=torch.float64, device=gdev) for _ in range(world)] if world > 1 else None
+
+    def gather():      # results to every rank: the only communication of the inference path (a few KB per step)
+        mine = torch.cat([b["out"][1] for b in buckets])
+        dist.all_gather(gathered, mine if args.backend == "nccl" else mine.cpu())
 
     def step():
         run_step(pe, buckets, streams)
-        if world > 1:   # results to every rank: the only communication of the inference path
-            dist.all_gather(gathered, torch.cat([b["out"][1] for b in buckets]))
+        if world > 1:
+            gather()
 
     run_step(pe, buckets)                      # eager pass: uploads weights, sizes the workspace
     torch.cuda.synchronize()
@@ -269,7 +281,7 @@ def main():
         if graph is not None:
             graph.replay()
             if world > 1:
-                dist.all_gather(gathered, torch.cat([b["out"][1] for b in buckets]))
+                gather()
         else:
             step()
 
@@ -286,7 +298,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=gdev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
