@@ -1,0 +1,100 @@
+#!/usr/bin/env python
+"""LineMOD evaluation driver -- the job of the reference's tools/eval_linemod.py on the HIP path.
+
+    python tools/eval_linemod.py --dataset_root <Linemod_preprocessed> --model <pose_model.pth> --refine_model <refine.pth>
+
+For every test frame: PoseNet -> arg-max pose -> ``iteration`` (4) refine steps in one device call
+(PoseEstimator), then ADD (ADD-S through the fused 1-NN for the symmetric objects eggbox / glue) on the
+device (``add_metric``) against ``0.1 x diameter`` from ``models_info.yml`` (tools/eval_linemod.py:57-61,
+118-139); per-object and overall success rates go to ``eval_result_logs.txt`` in the reference's format.
+
+The LineMOD loader itself (PNG / yml / ply reading, SegNet masks, OpenCV contour boxes) is dataset tooling
+outside this build's scope: the script imports ``datasets.linemod.dataset.PoseDataset`` from the PYTHONPATH
+(the reference's loader works unchanged; any object with the same ``__getitem__`` 6-tuple,
+``get_sym_list()`` and ``get_num_points_mesh()`` does).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import torch
+import yaml
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from densefusion_amd.lib.metric import add_metric  # noqa: E402
+from densefusion_amd.lib.network import PoseEstimator, PoseNet, PoseRefineNet  # noqa: E402
+
+OBJLIST = [1, 2, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14, 15]
+
+
+def build_parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dataset_root", type=str, default="", help="dataset root dir")
+    ap.add_argument("--model", type=str, default="", help="resume PoseNet model")
+    ap.add_argument("--refine_model", type=str, default="", help="resume PoseRefineNet model")
+    ap.add_argument("--dataset_config_dir", type=str, default="datasets/linemod/dataset_config")
+    ap.add_argument("--output_result_dir", type=str, default="experiments/eval_result/linemod")
+    ap.add_argument("--num_points", type=int, default=500)
+    ap.add_argument("--iteration", type=int, default=4)
+    ap.add_argument("--max_frames", type=int, default=0)
+    return ap
+
+
+def evaluate(testdataset, estimator, refiner, diameter, opt, fw=None):
+    """The loop of tools/eval_linemod.py:68-139; returns (success_count, num_count) per object."""
+    num_objects = len(diameter)
+    pe = PoseEstimator(estimator, refiner)
+    sym_list = testdataset.get_sym_list()
+    success_count, num_count = [0] * num_objects, [0] * num_objects
+    say = (lambda m: (print(m), fw.write(m + "\n"))) if fw else print
+    n = len(testdataset) if opt.max_frames <= 0 else min(opt.max_frames, len(testdataset))
+    for i in range(n):
+        points, choose, img, target, model_points, idx = testdataset[i]
+        if points.dim() == 1:                     # the loader's "no mask pixel" sentinel (datasets/linemod/dataset.py:135-137)
+            say("No.{0} NOT Pass! Lost detection!".format(i))
+            continue
+        dev = torch.device("cuda")
+        obj = int(idx.reshape(-1)[0])
+        _, pose = pe.estimate(img[None].to(dev), points[None].to(dev), choose.to(dev).reshape(1, 1, -1),
+                              idx.to(dev).reshape(1), opt.iteration)
+        dis = float(add_metric(pose, model_points[None].to(dev), target[None].to(dev), [1 if obj in sym_list else 0])[0])
+        if dis < diameter[obj]:
+            success_count[obj] += 1
+            say("No.{0} Pass! Distance: {1}".format(i, dis))
+        else:
+            say("No.{0} NOT Pass! Distance: {1}".format(i, dis))
+        num_count[obj] += 1
+    return success_count, num_count
+
+
+def main(argv=None, testdataset=None):
+    opt = build_parser().parse_args(argv)
+    num_objects = len(OBJLIST)
+    estimator = PoseNet(num_points=opt.num_points, num_obj=num_objects).cuda()
+    refiner = PoseRefineNet(num_points=opt.num_points, num_obj=num_objects).cuda()
+    estimator.load_state_dict(torch.load(opt.model, map_location="cuda", weights_only=True))
+    refiner.load_state_dict(torch.load(opt.refine_model, map_location="cuda", weights_only=True))
+    estimator.eval(); refiner.eval()
+    if testdataset is None:
+        from datasets.linemod.dataset import PoseDataset as PoseDataset_linemod
+        testdataset = PoseDataset_linemod("eval", opt.num_points, False, opt.dataset_root, 0.0, True)
+    with open("{0}/models_info.yml".format(opt.dataset_config_dir), "r") as f:
+        meta = yaml.safe_load(f)
+    diameter = [meta[obj]["diameter"] / 1000.0 * 0.1 for obj in OBJLIST]
+    print(diameter)
+    os.makedirs(opt.output_result_dir, exist_ok=True)
+    with open("{0}/eval_result_logs.txt".format(opt.output_result_dir), "w") as fw:
+        success_count, num_count = evaluate(testdataset, estimator, refiner, diameter, opt, fw)
+        for i in range(num_objects):
+            if num_count[i]:
+                m = "Object {0} success rate: {1}".format(OBJLIST[i], float(success_count[i]) / num_count[i])
+                print(m); fw.write(m + "\n")
+        m = "ALL success rate: {0}".format(float(sum(success_count)) / max(1, sum(num_count)))
+        print(m); fw.write(m + "\n")
+    return success_count, num_count
+
+
+if __name__ == "__main__":
+    main()
