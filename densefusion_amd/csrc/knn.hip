@@ -72,6 +72,58 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn1_dim3_kernel(const float *__res
   }
 }
 
+// dim == 3, k == 1, FEW queries: the query set alone cannot fill the chip, so the reference points are split
+// over the lanes as well.  A workgroup owns 64 queries x all R references: wave w scans the slice
+// r = w, w + WAVES, ... (ascending), every lane keeps its running arg-min, and the WAVES partial results per query
+// meet in LDS where lane order = slice order; the combine keeps the smaller distance and, on equal distances, the
+// lower reference index -- exactly the winner a single ascending scan with strict '<' would have kept.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void knn1_dim3_rsplit_kernel(const float *__restrict__ ref, int R,
+                                                                     const float *__restrict__ query, int Q,
+                                                                     int64_t *__restrict__ ind) {
+  extern __shared__ __attribute__((aligned(16))) float s_ref[];   // [R][4], then WAVES*64 (dist, idx) pairs
+  const int b = blockIdx.y;
+  ref += (size_t)b * 3 * R;
+  query += (size_t)b * 3 * Q;
+  ind += (size_t)b * Q;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int r = tid; r < R; r += WAVES * 64)
+    reinterpret_cast<float4 *>(s_ref)[r] = make_float4(ref[r], ref[R + r], ref[2 * R + r], 0.f);
+  float *s_d = s_ref + (size_t)R * 4;
+  int *s_i = reinterpret_cast<int *>(s_d + WAVES * 64);
+  __syncthreads();
+  const int q = blockIdx.x * 64 + lane;
+  const int qc = q < Q ? q : Q - 1;
+  const float qx = query[qc], qy = query[Q + qc], qz = query[2 * Q + qc];
+  float best = __builtin_inff();
+  int bi = 0x7fffffff;
+  for (int r = wave; r < R; r += WAVES) {
+    const float4 p = reinterpret_cast<const float4 *>(s_ref)[r];
+    const float tx = p.x - qx, ty = p.y - qy, tz = p.z - qz;
+    float d = tx * tx;
+    d = __builtin_fmaf(ty, ty, d);
+    d = __builtin_fmaf(tz, tz, d);
+    const bool lt = d < best;
+    best = lt ? d : best;
+    bi = lt ? r : bi;
+  }
+  s_d[wave * 64 + lane] = best;
+  s_i[wave * 64 + lane] = bi;
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) {
+      const float d = s_d[w * 64 + lane];
+      const int i = s_i[w * 64 + lane];
+      const bool take = d < best || (d == best && i < bi);
+      best = take ? d : best;
+      bi = take ? i : bi;
+    }
+    if (bi == 0x7fffffff) bi = 0;          // all-NaN column: row 0, like the reference's seed (.cu:120-122)
+    if (q < Q) ind[q] = (int64_t)bi + 1;
+  }
+}
+
 // Generic dim / k: one lane per query, sorted top-k kept in registers/scratch (stable: ties keep the
 // lower index first, which is what the reference's insertion with strict comparisons produces).
 template <int KMAX>
@@ -125,7 +177,11 @@ int launch_knn(const float *ref, const float *query, int64_t *idx, int batch, in
   if (batch == 0 || Q == 0) return DF_OK;      // empty query set: nothing to write
   if (!ref || !query || !idx) return df::set_error(DF_ERR_ARG, "knn: null pointer");
   if (batch > 65535) return df::set_error(DF_ERR_ARG, "knn: batch > 65535");
-  if (dim == 3 && k == 1 && (size_t)R * 16 <= 64 * 1024) {
+  if (dim == 3 && k == 1 && (size_t)R * 16 <= 56 * 1024 && (long)Q * batch <= 64L * 1024 && R >= 32) {
+    constexpr int WAVES = 16;     // 1024 threads: 64 queries x 16 reference slices per workgroup
+    dim3 grid(df::cdiv(Q, 64), batch);
+    hipLaunchKernelGGL(knn1_dim3_rsplit_kernel<WAVES>, grid, dim3(WAVES * 64), (size_t)R * 16 + WAVES * 64 * 8, st, ref, R, query, Q, idx);
+  } else if (dim == 3 && k == 1 && (size_t)R * 16 <= 64 * 1024) {
     // 4 queries per lane amortise the LDS broadcast reads best (measured 5.7 vs 5.4 Tpairs/s) but need
     // >= ~8 waves per SIMD-slot of work to fill the chip; smaller problems keep 2 per lane for more waves
     if ((long)Q * batch >= 4L * 1000 * 1000) {
