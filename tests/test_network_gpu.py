@@ -185,3 +185,19 @@ def test_results_do_not_depend_on_workspace_garbage(poison):
     p1 = pe.estimate(T("img"), T("cloud"), T("choose"), T("obj"), 2)
     for a, c in zip(r0 + p0, r1 + p1):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("H,W", [(100, 140), (88, 72)])
+def test_crop_sizes_that_are_not_multiples_of_8(H, W):
+    """The reference's feature map is 8*ceil-ish(H/8) wide for such crops and `choose` indexes THAT map
+    (lib/network.py:98-102 views it flat); the engine must reproduce the same geometry and values."""
+    K, N = 13, 500
+    est, ref = _nets(K, N, 12)
+    o = synth.make_object(77 + H, H, W, N, K, cam=synth.LINEMOD_CAM)
+    T = lambda k: torch.from_numpy(o[k])[None]
+    sdp = dfnet._to_torch_sd(synth.make_state_dict(synth.posenet_spec(K), 12))
+    with torch.no_grad():
+        want = dfnet.posenet_forward(sdp, T("img"), T("cloud"), torch.from_numpy(o["choose"]), torch.from_numpy(o["obj"]))
+    got = est(T("img").cuda(), T("cloud").cuda(), torch.from_numpy(o["choose"]).cuda(), torch.from_numpy(o["obj"]).cuda())
+    for a, b in zip(got, want):
+        _close(a, b.numpy())
