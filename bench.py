@@ -122,6 +122,38 @@ def measured_traffic():
         return None
 
 
+def bench_latency(est, ref, device):
+    """Single-object latency (B = 1, 160x160, N = 1000) of the whole path with 2 and 4 refine iterations, captured as
+    one hipGraph -- BASELINE configs[2] ("hipGraph-captured refine loop"); not part of `value`."""
+    o = synth.make_object(4242, 160, 160, N_PTS, K_OBJ)
+    d = {k: torch.from_numpy(o[k])[None].to(device) for k in ("img", "cloud", "choose", "obj")}
+    out = {}
+    for iters in (2, 4):
+        pe = PoseEstimator(est, ref)
+        res = (torch.empty(1, 7, dtype=torch.float64, device=device), torch.empty(1, 7, dtype=torch.float64, device=device))
+        pe.estimate(d["img"], d["cloud"], d["choose"], d["obj"], iters, out=res)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            pe.estimate(d["img"], d["cloud"], d["choose"], d["obj"], iters, out=res)
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(g):
+            pe.estimate(d["img"], d["cloud"], d["choose"], d["obj"], iters, out=res)
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 50
+        for _ in range(n):
+            g.replay()
+        torch.cuda.synchronize()
+        out[f"iters{iters}_ms"] = round((time.perf_counter() - t0) / n * 1e3, 3)
+    out["shape"] = "B=1, 160x160 crop, N=1000, hipGraph replay, wall clock per pose"
+    return out
+
+
 def bench_knn():
     R, Q = 500, 500000
     knn = KNearestNeighbor(1)
@@ -333,6 +365,7 @@ def main():
                            "gemm_ms_per_step": round(ms / max(1, min(args.steps, 5)), 3)}
         if not args.no_knn:
             out["knn"] = bench_knn()
+            out["latency_single_object"] = bench_latency(est, ref, device)
         if world == 1 and not args.no_cpu_baseline:
             gpu_poses = [b["out"][1].cpu().numpy() for b in buckets]
             out["cpu_baseline"], out["parity"] = cpu_baseline(buckets, gpu_poses)

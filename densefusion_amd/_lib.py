@@ -46,6 +46,17 @@ SIGNATURES = {
     "df_loss_refine_backward": (_i, [_vp] * 5 + [_i, _f] + [_vp] * 3),
     "df_add_metric": (_i, [_vp] * 4 + [_i, _i, _vp, _vp]),
     "df_ycb_distances": (_i, [_vp] * 3 + [_i, _i, _vp, _vp, _vp]),
+    "df_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    "df_maxpool3s2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "df_maxpool3s2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "df_adaptive_avgpool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "df_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "df_logsoftmax": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "df_dropout2d_mask": (_i, [_vp, _i64, ctypes.c_uint, _f, _vp]),
+    "df_channel_scale": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp]),
+    "df_gather_rows": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i, _vp]),
+    "df_colmean": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "df_sigmoid": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "df_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
     "df_preprocess_objects": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "df_conv2d_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp]),

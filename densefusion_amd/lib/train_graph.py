@@ -2,18 +2,19 @@
 
 The inference engine (csrc/engine.hip) fuses and folds layers in ways that have no stored activations;
 training instead walks the reference's layer graph (lib/extractors.py:114-124, lib/pspnet.py:64-77,
-lib/network.py:53-68,95-132,151-206) once more, with every GEMM-shaped layer -- all convolutions, the
-Conv1d(k=1) point MLPs and the Linear towers, >99 % of the FLOPs -- running forward, data-gradient and
-weight-gradient on the fp32-MFMA kernels through ``ops.ConvNHWC``, and torch autograd as the tape.
-The thin element-wise / resampling glue between them (ReLU, pooling, bilinear resize, LogSoftmax, gather,
-Dropout2d) still uses stock torch ops on channels-last views in this round.
+lib/network.py:53-68,95-132,151-206) once more.  torch.autograd is only the tape: every layer's forward and
+backward is a HIP launch -- convolutions / Conv1d(k=1) / Linear with their bias, residual and ReLU / PReLU fused
+on the fp32-MFMA kernels (``train_ops.ConvAct``: forward, activation gradient, data gradient, weight gradient),
+pooling, bilinear resize, LogSoftmax, Dropout2d, the colour-feature gather, the mean over points and the sigmoid
+through ``csrc/trainops.hip``.  What torch itself still does is tensor plumbing only: views, the channel
+concatenations and zero-padding of the 3-channel inputs / 63-channel translation head.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn.functional as F
 
-from ..ops import ConvNHWC
+from .. import train_ops as T
 
 _CNN = "cnn.model.module."
 
@@ -22,9 +23,10 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
-def conv(x, w, b=None, stride=1, pad=0, dil=1):
-    """x [B,H,W,Cin] channels-last; w in the REFERENCE layout [Cout,Cin,KH,KW] (or [Cout,Cin,1] / [Cout,Cin]).
-    Channel counts that are not multiples of 4 (3-channel image / cloud, 63 translation outputs) are zero-padded."""
+def conv(x, w, b=None, stride=1, pad=0, dil=1, act=0, res=None, slope=None):
+    """act(conv(x, w) + b + res).  x [B,H,W,Cin] channels-last; w in the REFERENCE layout [Cout,Cin,KH,KW] (or
+    [Cout,Cin,1] / [Cout,Cin]); act 0 none, 1 ReLU, 2 PReLU(slope).  Channel counts that are not multiples of 4
+    (3-channel image / cloud, 63 translation outputs) are zero-padded."""
     if w.dim() == 3:
         w = w.unsqueeze(-1)
     elif w.dim() == 2:
@@ -38,32 +40,23 @@ def conv(x, w, b=None, stride=1, pad=0, dil=1):
         w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, _pad4(cout) - cout))
         if b is not None:
             b = F.pad(b, (0, _pad4(cout) - cout))
-    y = ConvNHWC.apply(x, w.contiguous(), b.contiguous() if b is not None else None, stride, pad, dil)
+    y = T.ConvAct.apply(x, w.contiguous(), b.contiguous() if b is not None else None, res, slope, stride, pad, dil, act)
     return y[..., :cout] if cout % 4 else y
 
 
-def _nchw(x):
-    return x.permute(0, 3, 1, 2)           # logical NCHW view of channels-last memory
-
-
-def _nhwc(x):
-    return x.permute(0, 2, 3, 1).contiguous()
-
-
 def _basic_block(P, base, x, stride, dilation):
-    out = F.relu(conv(x, P[base + "conv1.weight"], None, stride, dilation, dilation))
-    out = conv(out, P[base + "conv2.weight"], None, 1, dilation, dilation)
+    out = conv(x, P[base + "conv1.weight"], None, stride, dilation, dilation, act=1)
     key = base + "downsample.0.weight"
     res = conv(x, P[key], None, stride, 0, 1) if key in P else x
-    return F.relu(out + res)
+    return conv(out, P[base + "conv2.weight"], None, 1, dilation, dilation, act=1, res=res)     # relu(conv2 + residual)
 
 
-def pspnet_forward(P, img, dropout):
+def pspnet_forward(P, img, dropout, seed=0):
     """img [B,3,H,W] -> log-softmax colour features [B,H,W,32] (channels-last)."""
     f = _CNN + "feats."
     x = img.permute(0, 2, 3, 1).contiguous()
-    x = F.relu(conv(x, P[f + "conv1.weight"], None, 2, 3, 1))
-    x = _nhwc(F.max_pool2d(_nchw(x), kernel_size=3, stride=2, padding=1))
+    x = conv(x, P[f + "conv1.weight"], None, 2, 3, 1, act=1)
+    x = T.MaxPool3s2.apply(x)
     for li, (stride, dil) in enumerate(((1, 1), (2, 1), (1, 2), (1, 4)), start=1):
         x = _basic_block(P, f"{f}layer{li}.0.", x, stride, 1)
         x = _basic_block(P, f"{f}layer{li}.1.", x, 1, dil)
@@ -71,43 +64,46 @@ def pspnet_forward(P, img, dropout):
     p = _CNN + "psp."
     priors = []
     for i, s in enumerate((1, 2, 3, 6)):
-        y = _nhwc(F.adaptive_avg_pool2d(_nchw(x), (s, s)))
+        y = T.AdaptiveAvgPool.apply(x, s)
         y = conv(y, P[f"{p}stages.{i}.1.weight"])
-        priors.append(_nhwc(F.interpolate(_nchw(y), size=(h, w), mode="bilinear", align_corners=False)))
+        priors.append(T.Bilinear.apply(y, h, w, False))
     priors.append(x)
-    x = F.relu(conv(torch.cat(priors, dim=3), P[p + "bottleneck.weight"], P[p + "bottleneck.bias"]))
+    x = conv(torch.cat(priors, dim=3), P[p + "bottleneck.weight"], P[p + "bottleneck.bias"], act=1)
     if dropout:
-        x = _nhwc(F.dropout2d(_nchw(x), p=0.3, training=True))
-    for name in ("up_1", "up_2", "up_3"):
+        x = T.Dropout2d.apply(x, 0.3, seed * 4 + 1)
+    for k, name in enumerate(("up_1", "up_2", "up_3")):
         q = f"{_CNN}{name}.conv."
-        x = _nhwc(F.interpolate(_nchw(x), scale_factor=2, mode="bilinear", align_corners=True))
-        x = F.prelu(conv(x, P[q + "1.weight"], P[q + "1.bias"], 1, 1, 1), P[q + "2.weight"])
+        x = T.Bilinear.apply(x, 2 * x.shape[1], 2 * x.shape[2], True)
+        x = conv(x, P[q + "1.weight"], P[q + "1.bias"], 1, 1, 1, act=2, slope=P[q + "2.weight"])
         if dropout and name != "up_3":
-            x = _nhwc(F.dropout2d(_nchw(x), p=0.15, training=True))
+            x = T.Dropout2d.apply(x, 0.15, seed * 4 + 2 + k)
     x = conv(x, P[_CNN + "final.0.weight"], P[_CNN + "final.0.bias"])
-    return F.log_softmax(x, dim=3)
+    return T.LogSoftmaxLast.apply(x)
 
 
 def _pc(P, key, x, relu=True):
     """Conv1d(k=1) over points: x [1,N,1,C]."""
-    y = conv(x, P[key + ".weight"], P[key + ".bias"])
-    return F.relu(y) if relu else y
+    return conv(x, P[key + ".weight"], P[key + ".bias"], act=1 if relu else 0)
+
+
+_DROPOUT_CALLS = [0]
 
 
 def posenet_forward(net, img, x, choose, obj, dropout=True):
     """Training-mode PoseNet.forward for ONE object (bs = 1, lib/network.py:95-132), differentiable."""
     P = dict(net.named_parameters())
     N = net.num_points
-    feat = pspnet_forward(P, img, dropout)                               # [1,H,W,32]
+    _DROPOUT_CALLS[0] += 1
+    feat = pspnet_forward(P, img, dropout, seed=int(torch.initial_seed() % 100003) * 7919 + _DROPOUT_CALLS[0])   # [1,H,W,32]
     idx = choose.reshape(-1)
-    emb_pm = feat.reshape(-1, 32)[idx]                                   # [N,32]  (gather at the chosen pixels)
+    emb_pm = T.GatherRows.apply(feat.reshape(-1, 32), idx)               # [N,32]  (gather at the chosen pixels)
     pts = x.reshape(1, N, 1, 3)
     e = emb_pm.reshape(1, N, 1, 32)
     x1, e1 = _pc(P, "feat.conv1", pts), _pc(P, "feat.e_conv1", e)
     x2, e2 = _pc(P, "feat.conv2", x1), _pc(P, "feat.e_conv2", e1)
     pf1, pf2 = torch.cat((x1, e1), 3), torch.cat((x2, e2), 3)
     x6 = _pc(P, "feat.conv6", _pc(P, "feat.conv5", pf2))
-    ap = x6.mean(dim=1, keepdim=True).expand(1, N, 1, 1024)             # AvgPool1d(N) + repeat
+    ap = T.ColMean.apply(x6.reshape(N, 1024)).reshape(1, 1, 1, 1024).expand(1, N, 1, 1024)    # AvgPool1d(N) + repeat
     ap_x = torch.cat((pf1, pf2, ap), 3)                                  # 128 + 256 + 1024
     outs = {}
     for hname in "rtc":
@@ -118,7 +114,7 @@ def posenet_forward(net, img, x, choose, obj, dropout=True):
     o = int(obj.reshape(-1)[0])
     out_rx = outs["r"][:, o * 4:o * 4 + 4].reshape(1, N, 4)
     out_tx = outs["t"][:, o * 3:o * 3 + 3].reshape(1, N, 3)
-    out_cx = torch.sigmoid(outs["c"][:, o:o + 1]).reshape(1, N, 1)
+    out_cx = T.Sigmoid.apply(outs["c"][:, o:o + 1].contiguous()).reshape(1, N, 1)
     emb = emb_pm.t().reshape(1, 32, N)
     return out_rx, out_tx, out_cx, emb.detach()
 
@@ -132,7 +128,7 @@ def refiner_forward(net, x, emb, obj):
     x1, e1 = _pc(P, "feat.conv1", pts), _pc(P, "feat.e_conv1", e)
     x2, e2 = _pc(P, "feat.conv2", x1), _pc(P, "feat.e_conv2", e1)
     pf3 = torch.cat((x1, e1, x2, e2), 3)
-    ap = _pc(P, "feat.conv6", _pc(P, "feat.conv5", pf3)).mean(dim=1, keepdim=True)     # [1,1,1,1024]
+    ap = T.ColMean.apply(_pc(P, "feat.conv6", _pc(P, "feat.conv5", pf3)).reshape(N, 1024)).reshape(1, 1, 1, 1024)
     outs = {}
     for hname in "rt":
         y = _pc(P, f"conv1_{hname}", ap)

@@ -136,6 +136,22 @@ int df_add_metric(const double *pose, const float *model_points, const float *ta
 int df_ycb_distances(const double *rt_est, const double *rt_gt, const double *pts, int B, int M, double *add_out,
                      double *adi_out, df_stream_t stream);
 
+/* Element-wise / resampling layers of the training graph (channels-last fp32), forward and backward; `backward != 0`
+ * selects the adjoint (in = upstream gradient, out = input gradient).  See csrc/trainops.hip for the reference lines. */
+int df_act_bwd(const float *dy, const float *y, float *dx, int64_t n, int act /*1 ReLU, 2 PReLU*/, const float *slope,
+               float *dslope /* PReLU: += */, df_stream_t stream);
+int df_maxpool3s2_fwd(const float *x, float *y, int B, int H, int W, int C, int OH, int OW, df_stream_t stream);
+int df_maxpool3s2_bwd(const float *x, const float *dy, float *dx, int B, int H, int W, int C, int OH, int OW, df_stream_t stream);
+int df_adaptive_avgpool(const float *in, float *out, int B, int H, int W, int C, int s, int backward, df_stream_t stream);
+int df_bilinear(const float *in, float *out, int B, int H, int W, int C, int OH, int OW, int align_corners, int backward,
+                df_stream_t stream);
+int df_logsoftmax(const float *x_or_dy, const float *y, float *out, int64_t rows, int C, int backward, df_stream_t stream);
+int df_dropout2d_mask(float *scale, int64_t n /* B*C */, unsigned seed, float p, df_stream_t stream);
+int df_channel_scale(const float *x, const float *scale /*[B][C]*/, float *y, int B, int64_t hw, int C, df_stream_t stream);
+int df_gather_rows(const float *in, const int64_t *idx, float *out, int64_t n, int C, int64_t rows, int backward, df_stream_t stream);
+int df_colmean(const float *in, float *out, int64_t rows, int C, int backward, df_stream_t stream);
+int df_sigmoid(const float *x_or_dy, const float *y, float *out, int64_t n, int backward, df_stream_t stream);
+
 /* Adam update of a flat fp32 parameter buffer (the optimizer of tools/train.py:99 with its default betas / eps):
  *   m = m + (1-b1)(g' - m);  v = b2 v + (1-b2) g'^2;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps),  g' = grad_scale * g
  * grad_scale carries the 1/(ranks x accumulated samples) of the data-parallel gradient average. */
