@@ -6,7 +6,10 @@ from densefusion_amd.lib.knn import KNearestNeighbor
 
 def main():
     knn = KNearestNeighbor(1)
-    for (B, R, Q) in [(1, 500, 500000), (1, 500, 1000000), (8, 500, 1000000), (1, 2600, 2600), (1, 500, 500)]:
+    sizes = [(1, 500, 500000), (1, 500, 1000000), (8, 500, 1000000), (1, 2600, 2600), (1, 500, 500)]
+    if len(sys.argv) == 4:                                     # one size only (for rocprofv3 --pmc passes)
+        sizes = [tuple(int(a) for a in sys.argv[1:4])]
+    for (B, R, Q) in sizes:
         ref = (torch.rand(B, 3, R, device="cuda") - 0.5) * 0.2
         qry = (torch.rand(B, 3, Q, device="cuda") - 0.5) * 0.25
         for _ in range(3):
