@@ -58,7 +58,7 @@ SIGNATURES = {
     "df_colmean": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "df_sigmoid": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "df_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
-    "df_preprocess_objects": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "df_preprocess_objects": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "df_conv2d_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp]),
     "df_conv2d_dgrad_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),
     "df_conv2d_wgrad_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),

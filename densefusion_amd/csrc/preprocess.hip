@@ -47,7 +47,7 @@ struct ObjDesc {   // one object: frame index and snapped bounding box (host sid
 __global__ __launch_bounds__(PB) void preprocess_kernel(const unsigned char *__restrict__ rgb, const unsigned short *__restrict__ depth,
                                                         const int *__restrict__ label, const ObjDesc *__restrict__ objs, int IH,
                                                         int IW, int H, int W, int N, float cx, float cy, float fx, float fy,
-                                                        float cam_scale, int *__restrict__ nz_scratch, float *__restrict__ img,
+                                                        float cam_scale, float cloud_div, int *__restrict__ nz_scratch, float *__restrict__ img,
                                                         float *__restrict__ cloud, int64_t *__restrict__ choose,
                                                         int *__restrict__ count_out) {
   __shared__ int s_scan[PB];
@@ -130,9 +130,11 @@ __global__ __launch_bounds__(PB) void preprocess_kernel(const unsigned char *__r
     const int r = o.rmin + i / W, c = o.cmin + i % W;
     const float d = (float)depth[fbase + (size_t)r * IW + c];
     const float pt2 = d / cam_scale;
-    cl[j * 3 + 0] = ((float)c - cx) * pt2 / fx;
-    cl[j * 3 + 1] = ((float)r - cy) * pt2 / fy;
-    cl[j * 3 + 2] = pt2;
+    // cloud_div: the LineMOD loader back-projects in depth units and divides the finished cloud by 1000
+    // (datasets/linemod/dataset.py:152-157); the YCB path passes 1 (x / 1 == x)
+    cl[j * 3 + 0] = ((float)c - cx) * pt2 / fx / cloud_div;
+    cl[j * 3 + 1] = ((float)r - cy) * pt2 / fy / cloud_div;
+    cl[j * 3 + 2] = pt2 / cloud_div;
   }
   // 4. normalised colour crop, CHW (eval_ycb.py:175-181)
   float *im = img + (size_t)b * 3 * HW;
@@ -152,14 +154,14 @@ using namespace df;
 
 extern "C" int df_preprocess_objects(const unsigned char *rgb, const unsigned short *depth, const int *label, int num_frames,
                                      int IH, int IW, const int *obj_desc, int B, int H, int W, int num_points, float cam_cx,
-                                     float cam_cy, float cam_fx, float cam_fy, float cam_scale, int *scratch, float *img_out,
+                                     float cam_cy, float cam_fx, float cam_fy, float cam_scale, float cloud_div, int *scratch, float *img_out,
                                      float *cloud_out, int64_t *choose_out, int *count_out, df_stream_t stream) {
   if (!rgb || !depth || !label || !obj_desc || !scratch || !img_out || !cloud_out || !choose_out || !count_out)
     return set_error(DF_ERR_ARG, "preprocess: null pointer");
-  if (B <= 0 || num_frames <= 0 || H <= 0 || W <= 0 || H > IH || W > IW || num_points <= 0)
+  if (B <= 0 || num_frames <= 0 || H <= 0 || W <= 0 || H > IH || W > IW || num_points <= 0 || !(cam_scale > 0.f) || !(cloud_div > 0.f))
     return set_error(DF_ERR_ARG, "preprocess: bad sizes");
   hipLaunchKernelGGL(preprocess_kernel, dim3(B), dim3(PB), 0, to_stream(stream), rgb, depth, label,
                      reinterpret_cast<const ObjDesc *>(obj_desc), IH, IW, H, W, num_points, cam_cx, cam_cy, cam_fx, cam_fy, cam_scale,
-                     scratch, img_out, cloud_out, choose_out, count_out);
+                     cloud_div, scratch, img_out, cloud_out, choose_out, count_out);
   return check_launch("preprocess");
 }

@@ -15,6 +15,8 @@ from .. import _lib
 BORDER_LIST = [-1, 40, 80, 120, 160, 200, 240, 280, 320, 360, 400, 440, 480, 520, 560, 600, 640, 680]
 IMG_WIDTH, IMG_LENGTH = 480, 640            # eval_ycb.py:43-44 (rows, columns)
 YCB_CAM = dict(cx=312.9869, cy=241.3109, fx=1066.778, fy=1067.487, scale=10000.0)     # eval_ycb.py:37-41
+# datasets/linemod/dataset.py:73-76,152-157: back-projection in millimetres (cam_scale 1), finished cloud / 1000
+LINEMOD_CAM = dict(cx=325.26110, cy=242.04899, fx=572.41140, fy=573.57043, scale=1.0, cloud_div=1000.0)
 
 
 def _snap(extent):
@@ -74,7 +76,7 @@ def preprocess_objects(rgb, depth, label, objects, num_points, cam=YCB_CAM):
     count = torch.empty(B, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         st = _lib.lib().df_preprocess_objects(rgb.data_ptr(), depth.data_ptr(), label.data_ptr(), F, IH, IW, d_desc.data_ptr(), B,
-                                              H, W, num_points, cam["cx"], cam["cy"], cam["fx"], cam["fy"], cam["scale"],
+                                              H, W, num_points, cam["cx"], cam["cy"], cam["fx"], cam["fy"], cam["scale"], cam.get("cloud_div", 1.0),
                                               scratch.data_ptr(), img.data_ptr(), cloud.data_ptr(), choose.data_ptr(),
                                               count.data_ptr(), _lib.current_stream())
     _lib.check(st, "preprocess_objects")

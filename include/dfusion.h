@@ -168,10 +168,12 @@ int df_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
  *   scratch: B*H*W int32.  Outputs: img_out [B][3][H][W], cloud_out [B][N][3], choose_out [B][N] int64,
  *   count_out [B] = number of mask pixels (0 = detector lost the object, eval_ycb.py:234-237).
  * Subset rule when count > N (replaces np.random.shuffle, whose stream a GPU cannot share): keep the N mask
- * pixels with the smallest mix32(seed, flat index) keys, in index order -- a uniformly random ordered subset. */
+ * pixels with the smallest mix32(seed, flat index) keys, in index order -- a uniformly random ordered subset.
+ * cloud = ((col - cx) * z / fx, (row - cy) * z / fy, z) / cloud_div with z = depth / cam_scale: YCB passes (10000, 1)
+ * (eval_ycb.py:165-173), LineMOD (1, 1000) and itemid 255 (datasets/linemod/dataset.py:106-112,152-157). */
 int df_preprocess_objects(const unsigned char *rgb, const unsigned short *depth, const int *label, int num_frames, int IH,
                           int IW, const int *obj_desc, int B, int H, int W, int num_points, float cam_cx, float cam_cy,
-                          float cam_fx, float cam_fy, float cam_scale, int *scratch, float *img_out, float *cloud_out,
+                          float cam_fx, float cam_fy, float cam_scale, float cloud_div, int *scratch, float *img_out, float *cloud_out,
                           int64_t *choose_out, int *count_out, df_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -90,3 +90,27 @@ def test_knn_argument_errors(knn_cls):
     with pytest.raises(RuntimeError):
         knn_cls(11)(ref, torch.rand(1, 3, 10))          # k > ref_nb
     assert knn_cls(1)(ref, torch.rand(1, 3, 0)).shape == (1, 1, 0)   # empty query set
+
+
+def test_nn_distance_mirror_matches_golden_and_bruteforce():
+    """lib/nn.py:3-35 mirror: indices vs the reference-generated golden (0-based = golden - 1), distances and the
+    reverse direction vs a brute-force evaluation of the same definition."""
+    import os
+    import torch
+    from densefusion_amd.lib.nn import nn_distance
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "nn_distance_small.npz"))
+    pc1 = torch.from_numpy(g["query"]).transpose(2, 1).contiguous()          # [2,333,3]
+    pc2 = torch.from_numpy(g["ref"]).transpose(2, 1).contiguous()            # [2,70,3]
+    d1, i1, d2, i2 = nn_distance(pc1.cuda(), pc2.cuda())
+    assert i1.dtype == torch.int64 and tuple(i1.shape) == (2, 333) and tuple(i2.shape) == (2, 70)
+    assert np.array_equal(i1.cpu().numpy(), g["idx_1based"] - 1)
+    full = ((pc1[:, :, None, :] - pc2[:, None, :, :]) ** 2).sum(-1)           # the reference's [B,N,M] table, on the CPU
+    bd1, _ = full.min(dim=2)
+    bd2, bi2 = full.min(dim=1)
+    np.testing.assert_allclose(d1.cpu().numpy(), bd1.numpy(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(d2.cpu().numpy(), bd2.numpy(), rtol=1e-6, atol=1e-9)
+    assert np.array_equal(i2.cpu().numpy(), bi2.numpy())
+    with pytest.raises(NotImplementedError):
+        nn_distance(pc1.cuda(), pc2.cuda(), l1=True)

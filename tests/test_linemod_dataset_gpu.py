@@ -1,0 +1,145 @@
+"""GPU: the LineMOD ``PoseDataset`` mirror (host decode + device preparation) on a fabricated dataset tree, against the
+numpy restatement of datasets/linemod/dataset.py:90-195 (oracle/linemod_ref.py); then tools/eval_linemod.py reading
+that tree end to end."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+import yaml
+from PIL import Image
+
+from densefusion_amd import synth
+from oracle import linemod_ref
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJLIST = [1, 2, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14, 15]
+
+
+def _write_ply(path, pts):
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\ncomment fabricated\nelement vertex %d\n" % len(pts))
+        f.write("property float x\nproperty float y\nproperty float z\nproperty uchar red\nend_header\n")
+        for p in pts:
+            f.write("%.6f %.6f %.6f 255\n" % (p[0], p[1], p[2]))
+
+
+def make_tree(root, frames_per_obj=12, seed=0):
+    """A LineMOD-shaped tree: 13 objects, a few 480x640 frames each (blob mask + a distractor blob, depth with holes)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    os.makedirs(f"{root}/models")
+    for obj in OBJLIST:
+        sub = "%02d" % obj
+        for d in ("rgb", "depth", "mask"):
+            os.makedirs(f"{root}/data/{sub}/{d}")
+        os.makedirs(f"{root}/segnet_results/{sub}_label")
+        _write_ply(f"{root}/models/obj_{sub}.ply", rng.uniform(-60, 60, size=(640, 3)))
+        names, gt = [], {}
+        for k in range(frames_per_obj):
+            name = "%04d" % (k * 3)
+            names.append(name)
+            rgb = rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
+            depth = rng.integers(400, 1500, size=(480, 640)).astype(np.uint16)
+            depth[rng.random((480, 640)) < 0.1] = 0
+            mask = np.zeros((480, 640), dtype=np.uint8)
+            bh, bw = int(rng.integers(30, 170)), int(rng.integers(30, 220))
+            r0, c0 = int(rng.integers(0, 480 - bh)), int(rng.integers(0, 640 - bw))
+            if k == 1:
+                r0, c0 = 0, 640 - bw                      # box touching two frame edges
+            blob = rng.random((bh, bw)) < (0.9 if k != 2 else 0.02)       # frame 2: fewer mask pixels than num_points -> wrap padding
+            blob[0, :] = blob[-1, :] = True
+            blob[:, 0] = blob[:, -1] = True
+            mask[r0:r0 + bh, c0:c0 + bw][blob] = 255
+            lab = mask.copy()
+            lab[5:12, 5:11] = 255                         # a small false-positive blob in the segmentation result
+            if k == 3:
+                lab[:] = 0                                # segmentation lost the object
+            Image.fromarray(rgb).save(f"{root}/data/{sub}/rgb/{name}.png")
+            Image.fromarray(depth).save(f"{root}/data/{sub}/depth/{name}.png")
+            Image.fromarray(np.stack([mask] * 3, axis=2)).save(f"{root}/data/{sub}/mask/{name}.png")
+            Image.fromarray(lab).save(f"{root}/segnet_results/{sub}_label/{name}_label.png")
+            R = synth.quat_to_rot(synth.random_unit_quaternion(rng))
+            entry = {"cam_R_m2c": [float(v) for v in R.reshape(-1)], "cam_t_m2c": [float(v) for v in rng.uniform(-100, 100, 3) + [0, 0, 900]],
+                     "obj_bb": [c0, r0, bw, bh], "obj_id": obj}
+            gt[k * 3] = [{"cam_R_m2c": [0.0] * 9, "cam_t_m2c": [0.0] * 3, "obj_bb": [1, 1, 50, 50], "obj_id": 9}, entry] if obj == 2 else [entry]
+        for lst in ("train", "test"):
+            with open(f"{root}/data/{sub}/{lst}.txt", "w") as f:
+                f.write("\n".join(names) + "\n")
+        with open(f"{root}/data/{sub}/gt.yml", "w") as f:
+            yaml.safe_dump(gt, f)
+    return root
+
+
+@pytest.fixture(scope="module")
+def tree(tmp_path_factory):
+    return make_tree(str(tmp_path_factory.mktemp("linemod")))
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+@pytest.mark.parametrize("mode", ["eval", "test"])
+def test_dataset_matches_restatement(tree, mode):
+    _dev()
+    from densefusion_amd.datasets.linemod.dataset import PoseDataset
+    N = 500
+    ds = PoseDataset(mode, N, False, tree, 0.0, True, seed=7)
+    assert len(ds) == (13 * 12 if mode == "eval" else 13 * 1)            # 'test' keeps every 10th line of each list
+    assert ds.get_sym_list() == [7, 8] and ds.get_num_points_mesh() == 500
+    idxs = list(range(0, len(ds), 5 if mode == "eval" else 1))[:24]
+    random.seed(99)
+    got = ds.batch(idxs)
+    random.seed(99)
+    lost = 0
+    for i, g in zip(idxs, got):
+        obj, rank = ds.list_obj[i], ds.list_rank[i]
+        meta = ds._meta(obj, rank)
+        assert meta["obj_id"] == obj
+        rgb = np.array(Image.open(ds.list_rgb[i]))
+        depth = np.array(Image.open(ds.list_depth[i]))
+        label = np.array(Image.open(ds.list_label[i]))
+        for _ in range(3):
+            random.uniform(0.0, 0.0)
+        n = len(ds.pt[obj])
+        want = linemod_ref.get_item(rgb, depth, label, mode, meta, ds.pt[obj], list(range(n)), N, (7 * 1000003 + i) & 0xFFFFFFFF)
+        if want is None:
+            assert g[0].numel() == 1 and all(t.numel() == 1 for t in g)
+            lost += 1
+            continue
+        drop = set(random.sample(range(n), n - 500))
+        keep = [j for j in range(n) if j not in drop]
+        cloud, choose, img, target_all, model_all, box = want
+        assert tuple(g[2].shape[1:]) == (box[1] - box[0], box[3] - box[2])
+        assert torch.equal(g[1].cpu(), torch.from_numpy(choose))
+        assert torch.equal(g[0].cpu(), torch.from_numpy(cloud))                   # same fp32 operation order -> same bits
+        assert torch.equal(g[2].cpu(), torch.from_numpy(img))
+        np.testing.assert_array_equal(g[4].cpu().numpy(), model_all[keep])
+        np.testing.assert_allclose(g[3].cpu().numpy(), target_all[keep], rtol=0, atol=1e-7)
+        assert int(g[5][0]) == OBJLIST.index(obj)
+    if mode == "eval":
+        assert lost >= 1                                                           # the blanked segmentation frames
+    one = ds[idxs[0]]
+    assert torch.equal(one[0], got[0][0]) and torch.equal(one[1], got[0][1])
+
+
+def test_eval_linemod_from_disk(tree, tmp_path):
+    _dev()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import eval_linemod
+    K, N = 13, 500
+    sdp, sdr = synth.make_state_dict(synth.posenet_spec(K), 31), synth.make_state_dict(synth.refiner_spec(K), 1031)
+    torch.save({k: torch.from_numpy(v) for k, v in sdp.items()}, tmp_path / "p.pth")
+    torch.save({k: torch.from_numpy(v) for k, v in sdr.items()}, tmp_path / "r.pth")
+    os.makedirs(tmp_path / "cfg")
+    yaml.safe_dump({o: {"diameter": 400.0 + 10 * o} for o in OBJLIST}, open(tmp_path / "cfg" / "models_info.yml", "w"))
+    succ, cnt = eval_linemod.main(["--dataset_root", tree, "--model", str(tmp_path / "p.pth"), "--refine_model", str(tmp_path / "r.pth"),
+                                   "--dataset_config_dir", str(tmp_path / "cfg"), "--output_result_dir", str(tmp_path / "out"),
+                                   "--max_frames", "16"])
+    log = open(tmp_path / "out" / "eval_result_logs.txt").read().splitlines()
+    assert sum("Lost detection" in ln for ln in log) == 2                          # frames 3 and 15 of object 01 / 02
+    assert sum(cnt) == 14 and log[-1].startswith("ALL success rate")

@@ -8,10 +8,9 @@ For every test frame: PoseNet -> arg-max pose -> ``iteration`` (4) refine steps 
 device (``add_metric``) against ``0.1 x diameter`` from ``models_info.yml`` (tools/eval_linemod.py:57-61,
 118-139); per-object and overall success rates go to ``eval_result_logs.txt`` in the reference's format.
 
-The LineMOD loader itself (PNG / yml / ply reading, SegNet masks, OpenCV contour boxes) is dataset tooling
-outside this build's scope: the script imports ``datasets.linemod.dataset.PoseDataset`` from the PYTHONPATH
-(the reference's loader works unchanged; any object with the same ``__getitem__`` 6-tuple,
-``get_sym_list()`` and ``get_num_points_mesh()`` does).
+Frames come from ``densefusion_amd.datasets.linemod.dataset.PoseDataset`` (host PNG / yml / ply decoding, mask ->
+choose -> cloud -> crop on the device); any object with the same ``__getitem__`` 6-tuple, ``get_sym_list()`` and
+``get_num_points_mesh()`` can be injected instead (``main(testdataset=...)``).
 """
 from __future__ import annotations
 
@@ -78,7 +77,7 @@ def main(argv=None, testdataset=None):
     refiner.load_state_dict(torch.load(opt.refine_model, map_location="cuda", weights_only=True))
     estimator.eval(); refiner.eval()
     if testdataset is None:
-        from datasets.linemod.dataset import PoseDataset as PoseDataset_linemod
+        from densefusion_amd.datasets.linemod.dataset import PoseDataset as PoseDataset_linemod
         testdataset = PoseDataset_linemod("eval", opt.num_points, False, opt.dataset_root, 0.0, True)
     with open("{0}/models_info.yml".format(opt.dataset_config_dir), "r") as f:
         meta = yaml.safe_load(f)
