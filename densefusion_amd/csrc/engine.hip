@@ -15,6 +15,7 @@
 
 #include "igemm.h"
 #include "layers.h"
+#include "wino.h"
 #include "pose.h"
 
 namespace df {
@@ -203,6 +204,13 @@ static int load_param(Net &n, const std::string &key, const float *src, int64_t 
       hipDeviceSynchronize();
       hipFree(tmp);
     }
+    if (e == hipSuccess && key.find("feats.layer") != std::string::npos && HW == 9 && I >= 256 && I % 4 == 0 && O % 4 == 0) {
+      // stride-1 3x3 convs of layer3 / layer4 may run in the Winograd domain: transformed copy [16][O][I] (fp64 math)
+      float *U = dev_alloc(n, key + ".wino", (size_t)16 * O * I);
+      if (!U) return set_error(DF_ERR_LAUNCH, "load_param: hipMalloc failed");
+      launch_wino_weight(dst, U, O, I, 0);
+      hipDeviceSynchronize();
+    }
     if (e == hipSuccess && key.find(".up_") != std::string::npos && HW == 9) {
       // PSPUpsample convs run as low-resolution 1x1 products per tap: keep a tap-major copy [9][O][I]
       float *tm = dev_alloc(n, key + ".tm", (size_t)9 * O * I);
@@ -277,7 +285,7 @@ struct Ctx {
   hipStream_t st;
   bool dry;          // dry run: only measure the workspace
   char *base;
-  size_t off = 0, cap = 0;
+  size_t off = 0, cap = 0, peak = 0;   // peak: high-water mark (scratch regions are released and reused, see wino_conv)
   int err = DF_OK;
 
   float *f(size_t floats) { return reinterpret_cast<float *>(bytes(floats * sizeof(float))); }
@@ -285,6 +293,7 @@ struct Ctx {
     b = (b + 255) & ~size_t(255);
     void *p = dry ? nullptr : base + off;
     off += b;
+    if (off > peak) peak = off;
     if (!dry && off > cap && err == DF_OK) err = set_error(DF_ERR_WORKSPACE, "workspace too small: need > %zu bytes, have %zu", off, cap);
     return p;
   }
@@ -322,6 +331,30 @@ struct Ctx {
     if (rc != DF_OK) err = rc;
   }
 };
+
+static ConvParams point_gemm(const float *in, int in_ld, int in_coff, int cin, const float *w, const float *bias,
+                             float *out, int out_ld, int out_coff, int cout, int rows, int act);
+
+static bool wino_enabled() {
+  static const bool on = getenv("DF_NO_WINOGRAD") == nullptr;      // dev switch: A/B against the direct convolution
+  return on;
+}
+
+// 3x3 stride-1 pad=dil conv (+ residual, ReLU) as input transform -> 16 batched GEMMs -> output transform.
+// V / M scratch is taken from the workspace per call; the bump allocator position is restored afterwards so that
+// consecutive layers reuse the same (cache-resident) region.
+static void wino_conv(Ctx &c, const float *x, int B, int H, int W, int cin, int x_ld, const std::string &wkey, float *out, int cout,
+                      int out_ld, int out_coff, int dil, const float *res, int res_ld, int act) {
+  const WinoGeom g = wino_geom(B, H, W, dil);
+  const size_t mark = c.off;
+  float *V = c.f((size_t)16 * g.T * cin), *M = c.f((size_t)16 * g.T * cout);
+  if (c.live()) launch_wino_input(x, x_ld, 0, V, B, H, W, cin, dil, c.st);
+  ConvParams p = point_gemm(V, cin, 0, cin, c.w(wkey + ".wino"), nullptr, M, cout, 0, cout, (int)g.T, ACT_NONE);
+  p.zcount = 16; p.z_in_coff = g.T * cin; p.z_wgt = (long)cout * cin; p.z_out_coff = g.T * cout;
+  c.conv(p);
+  if (c.live()) launch_wino_output(M, out, out_ld, out_coff, res, res_ld, 0, act, B, H, W, cout, dil, c.st);
+  c.off = mark;
+}
 
 static ConvParams point_gemm(const float *in, int in_ld, int in_coff, int cin, const float *w, const float *bias,
                              float *out, int out_ld, int out_coff, int cout, int rows, int act) {
@@ -367,13 +400,24 @@ static float *cnn_forward(Ctx &c, int B, int H, int W, const float *img, int &ou
 
   int h = H2, w = W2, cin = 64, x_ld = 64;
   const int planes_of[4] = {64, 128, 256, 512}, stride_of[4] = {1, 2, 1, 1}, dil_of[4] = {1, 1, 2, 4};
+  // conv3x3 (+ residual) + ReLU: direct implicit GEMM, or the Winograd-domain product where the layer geometry pays
+  auto conv3x3 = [&](const float *in, int ih, int iw, int ci, int in_ld, const std::string &key, float *out, int oh, int ow, int co,
+                     int stride, int dil, const float *res, int res_ld) {
+    if (wino_enabled() && stride == 1 && wino_pays(ih, iw, dil, ci, co)) {
+      wino_conv(c, in, B, ih, iw, ci, in_ld, key, out, co, co, 0, dil, res, res_ld, ACT_RELU);
+      return;
+    }
+    ConvParams p = conv2d(in, B, ih, iw, ci, in_ld, c.w(key), nullptr, out, oh, ow, co, co, 0, 3, stride, dil, dil, ACT_RELU);
+    p.res = res; p.res_ld = res_ld;
+    c.conv(p);
+  };
   for (int li = 1; li <= 4; ++li) {
     const int planes = planes_of[li - 1], s = stride_of[li - 1], d = dil_of[li - 1];
     const std::string base = P + "feats.layer" + std::to_string(li) + ".";
     // block 0: built without dilation (lib/extractors.py:107); carries the stride and the 1x1 downsample
     const int oh = conv_out(h, 3, s, 1, 1), ow = conv_out(w, 3, s, 1, 1);
     float *t = c.f((size_t)B * oh * ow * planes);
-    c.conv(conv2d(x, B, h, w, cin, x_ld, c.w(base + "0.conv1.weight"), nullptr, t, oh, ow, planes, planes, 0, 3, s, 1, 1, ACT_RELU));
+    conv3x3(x, h, w, cin, x_ld, base + "0.conv1.weight", t, oh, ow, planes, s, 1, nullptr, 0);
     const float *res = x;
     int res_ld = x_ld;
     if (cin != planes || s != 1) {
@@ -383,23 +427,13 @@ static float *cnn_forward(Ctx &c, int B, int H, int W, const float *img, int &ou
       res_ld = planes;
     }
     float *o0 = c.f((size_t)B * oh * ow * planes);
-    {
-      ConvParams p = conv2d(t, B, oh, ow, planes, planes, c.w(base + "0.conv2.weight"), nullptr, o0, oh, ow, planes, planes, 0, 3, 1, 1, 1, ACT_RELU);
-      p.res = res; p.res_ld = res_ld;
-      c.conv(p);
-    }
+    conv3x3(t, oh, ow, planes, planes, base + "0.conv2.weight", o0, oh, ow, planes, 1, 1, res, res_ld);
     // block 1: dilated (lib/extractors.py:110)
     float *t1 = c.f((size_t)B * oh * ow * planes);
-    c.conv(conv2d(o0, B, oh, ow, planes, planes, c.w(base + "1.conv1.weight"), nullptr, t1, oh, ow, planes, planes, 0, 3, 1, d, d, ACT_RELU));
-    float *o1;
-    const int o1_ld = planes, o1_coff = 0;
-    o1 = c.f((size_t)B * oh * ow * planes);
-    {
-      ConvParams p = conv2d(t1, B, oh, ow, planes, planes, c.w(base + "1.conv2.weight"), nullptr, o1, oh, ow, planes, o1_ld, o1_coff, 3, 1, d, d, ACT_RELU);
-      p.res = o0; p.res_ld = planes;
-      c.conv(p);
-    }
-    x = o1; x_ld = o1_ld; h = oh; w = ow; cin = planes;
+    conv3x3(o0, oh, ow, planes, planes, base + "1.conv1.weight", t1, oh, ow, planes, 1, d, nullptr, 0);
+    float *o1 = c.f((size_t)B * oh * ow * planes);
+    conv3x3(t1, oh, ow, planes, planes, base + "1.conv2.weight", o1, oh, ow, planes, 1, d, o0, planes);
+    x = o1; x_ld = planes; h = oh; w = ow; cin = planes;
   }
   // PSP module (lib/pspnet.py:20-24) with the bottleneck folded through the pyramid:
   //   bottleneck(cat(up(W_s pool_s(f)), f)) = W_b[:,2048:] f + sum_s up((W_b[:,512s:512s+512] W_s) pool_s(f)) + b
@@ -442,8 +476,12 @@ static float *cnn_forward(Ctx &c, int B, int H, int W, const float *img, int &ou
 }
 
 // PoseNetFeat + heads (lib/network.py:53-68,107-131) on point-major rows padded to Npad per object
+// `sel` non-null (eval loop): only the confidence tower runs over all points; the r / t towers are evaluated at the
+// arg-max point alone (launch_head_select), which also writes the pose record -- out_r / out_t / out_c stay untouched.
+struct SelectOut { double *pose_wo, *state; float *rt; };
+
 static void posenet_points(Ctx &c, int B, int N, int Npad, const float *cloud, const float *emb_pm, const int64_t *obj,
-                           float *out_r, float *out_t, float *out_c) {
+                           float *out_r, float *out_t, float *out_c, const SelectOut *sel = nullptr) {
   Net &n = *c.net;
   const int rows = B * Npad;
   float *pf = c.f((size_t)rows * 384);          // [x1 64 | e1 64 | x2 128 | e2 128] = pointfeat_1 | pointfeat_2
@@ -467,6 +505,23 @@ static void posenet_points(Ctx &c, int B, int N, int Npad, const float *cloud, c
   // 1408-wide input are identical for every point of an object, so they collapse into a per-object bias
   float *gbias = c.f((size_t)B * 1920);
   if (c.live()) launch_linear_rows(apx, 1024, 0, c.w("head1.wg"), c.w("head1.bias"), gbias, 1920, B, 1024, 1920, 1, 0, c.st);
+  if (sel) {
+    float *h1c = c.f((size_t)rows * 640), *h2c = c.f((size_t)rows * 256), *h3c = c.f((size_t)rows * 128);
+    const float *w1 = c.w("head1.wpt"), *w2 = c.w("head2.w"), *b2 = c.w("head2.bias"), *w3 = c.w("head3.w"), *b3 = c.w("head3.bias");
+    if (c.err != DF_OK) return;
+    {
+      ConvParams p = point_gemm(pf, 384, 0, 384, c.dry ? nullptr : w1 + (size_t)2 * 640 * 384, c.dry ? nullptr : gbias + 1280, h1c, 640, 0, 640, rows, ACT_RELU);
+      p.rows_per_group = Npad; p.rows_valid = N; p.bias_group_ld = 1920;
+      c.conv(p);
+    }
+    c.conv(point_gemm(h1c, 640, 0, 640, c.dry ? nullptr : w2 + (size_t)2 * 256 * 640, c.dry ? nullptr : b2 + 512, h2c, 256, 0, 256, rows, ACT_RELU));
+    c.conv(point_gemm(h2c, 256, 0, 256, c.dry ? nullptr : w3 + (size_t)2 * 128 * 256, c.dry ? nullptr : b3 + 256, h3c, 128, 0, 128, rows, ACT_RELU));
+    if (c.live())
+      launch_head_select(h3c, c.w("conv4_c.weight"), c.w("conv4_c.bias"), pf, gbias, w1, w2, b2, w3, b3, c.w("conv4_r.weight"),
+                         c.w("conv4_r.bias"), c.w("conv4_t.weight"), c.w("conv4_t.bias"), obj, n.num_obj, cloud, B, N, Npad, sel->pose_wo,
+                         sel->state, sel->rt, nullptr, c.st);
+    return;
+  }
   float *h1 = c.f((size_t)rows * 1920);
   {
     ConvParams p = point_gemm(pf, 384, 0, 384, c.w("head1.wpt"), gbias, h1, 1920, 0, 1920, rows, ACT_RELU);
@@ -490,7 +545,7 @@ static void posenet_points(Ctx &c, int B, int N, int Npad, const float *cloud, c
 }
 
 static void posenet_forward(Ctx &c, int B, int H, int W, const float *img, const float *cloud, const int64_t *choose,
-                            const int64_t *obj, PoseNetOut &o) {
+                            const int64_t *obj, PoseNetOut &o, const SelectOut *sel = nullptr) {
   const int N = c.net->num_points, Npad = round_up(N, 128);
   int fh = 0, fw = 0;
   float *y3 = cnn_forward(c, B, H, W, img, fh, fw);      // fh x fw = the half-resolution grid of up_3's input
@@ -499,7 +554,7 @@ static void posenet_forward(Ctx &c, int B, int H, int W, const float *img, const
     launch_gather_final_logsoftmax(y3, c.w(std::string(CNN) + "up_3.conv.1.bias"), c.w(std::string(CNN) + "up_3.conv.2.weight"), choose,
                                    c.w(std::string(CNN) + "final.0.weight"), c.w(std::string(CNN) + "final.0.bias"), o.emb,
                                    o.emb_pm, B, fh, fw, N, Npad, c.st);
-  posenet_points(c, B, N, Npad, cloud, o.emb_pm, obj, o.out_r, o.out_t, o.out_c);
+  posenet_points(c, B, N, Npad, cloud, o.emb_pm, obj, o.out_r, o.out_t, o.out_c, sel);
 }
 
 // PoseRefineNetFeat + FC towers (lib/network.py:151-168,187-204).  The emb branch (e_conv1/e_conv2) does
@@ -653,7 +708,7 @@ extern "C" size_t df_posenet_workspace_bytes(const df_net *h, int B, int H, int 
   Ctx c{const_cast<Net *>(as_net(h)), nullptr, true, nullptr};
   PoseNetOut o{};
   posenet_forward(c, B, H, W, nullptr, nullptr, nullptr, nullptr, o);
-  return c.off;
+  return c.peak;
 }
 
 extern "C" int df_posenet_forward(df_net *h, int B, int H, int W, const float *img, const float *cloud,
@@ -684,7 +739,7 @@ extern "C" size_t df_refiner_workspace_bytes(const df_net *h, int B) {
   if (!h || as_net(h)->kind != 1 || B <= 0) return 0;
   Ctx c{const_cast<Net *>(as_net(h)), nullptr, true, nullptr};
   refiner_standalone(c, B, nullptr, nullptr, nullptr, nullptr, nullptr);
-  return c.off;
+  return c.peak;
 }
 
 extern "C" int df_refiner_forward(df_net *h, int B, const float *x, const float *emb, const int64_t *obj, float *out_r,
@@ -706,14 +761,16 @@ static void estimate(Ctx &cp, Ctx &cr, int B, int H, int W, const float *img, co
                      const int64_t *obj, int iters, double *pose_wo, double *pose) {
   const int N = cp.net->num_points, Npad = round_up(N, 128);
   PoseNetOut o{};
-  o.out_r = cp.f((size_t)B * N * 4); o.out_t = cp.f((size_t)B * N * 3); o.out_c = cp.f((size_t)B * N);
   o.emb = cp.f((size_t)B * 32 * N);
   double *state = reinterpret_cast<double *>(cp.bytes((size_t)B * 7 * sizeof(double)));
   float *rt = cp.f((size_t)B * 12);
-  posenet_forward(cp, B, H, W, img, cloud, choose, obj, o);
-  if (cp.live()) launch_pose_select(o.out_r, o.out_t, o.out_c, cloud, B, N, pose_wo, state, rt, nullptr, cp.st);
+  // eval_ycb.py:193-203 reads the r / t heads at the arg-max-confidence point only: confidence tower for all points,
+  // r / t towers for that one point (posenet_points, `sel`)
+  const SelectOut sel{pose_wo, state, rt};
+  posenet_forward(cp, B, H, W, img, cloud, choose, obj, o, &sel);
   // the refiner context continues in the same workspace
   cr.off = cp.off;
+  cr.peak = cp.peak;
   RefinerBufs r = refiner_alloc(cr, B, N, Npad);
   if (iters > 0) refiner_prepare(cr, r, B, Npad, o.emb_pm);
   for (int it = 0; it < iters; ++it)
@@ -725,7 +782,7 @@ extern "C" size_t df_estimate_workspace_bytes(const df_net *pn, const df_net *rf
   if (posenet_args_ok(as_net(pn), B, H, W) != DF_OK || !rf || as_net(rf)->kind != 1) return 0;
   Ctx cp{const_cast<Net *>(as_net(pn)), nullptr, true, nullptr}, cr{const_cast<Net *>(as_net(rf)), nullptr, true, nullptr};
   estimate(cp, cr, B, H, W, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr);
-  return cr.off;
+  return cr.peak;
 }
 
 extern "C" int df_estimate_poses(df_net *pn, df_net *rf, int B, int H, int W, const float *img, const float *cloud,

@@ -154,11 +154,147 @@ __global__ __launch_bounds__(64) void refiner_tail_kernel(const float *__restric
   write_rt(Mn, st + 4, rt + b * 12);
 }
 
+
+// ---- confidence-first head evaluation (eval loop only) -------------------------------------------------------------
+// tools/eval_ycb.py:193-203 uses pred_r / pred_t at ONE pixel per object -- the arg-max of the confidence -- so the
+// r and t towers (lib/network.py:107-121) need evaluating at that pixel only.  The engine runs the confidence tower
+// for all N points as GEMMs; this kernel finishes the job: conv4_c + sigmoid + arg-max over the N points (the same
+// expression and summation order as head_final_kernel, so the same winner as the full forward), then conv1..conv4 of
+// tower blockIdx.y (0 = r, 1 = t) for the winning point as wave-per-output dot products, then the pose record.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct HeadSel {
+  const float *h3c;                       // [rows][128] confidence-tower features
+  const float *w_c, *b_c;                 // conv4_c [K][128], [K]
+  const float *pf;                        // [rows][384] pointfeat_1 | pointfeat_2
+  const float *gbias;                     // [B][1920] global-feature part of head layer 1 (+ bias), towers r|t|c
+  const float *w1;                        // [1920][384] per-point part of head layer 1
+  const float *w2, *b2;                   // [3][256][640], [768]
+  const float *w3, *b3;                   // [3][128][256], [384]
+  const float *w_r, *b_r, *w_t, *b_t;     // conv4_r [4K][128], conv4_t [3K][128]
+  const int64_t *obj;
+  const float *cloud;                     // [B][N][3]
+  int num_obj, N, Npad;
+  double *pose_wo, *state;
+  float *rt;
+  int *which;
+};
+
+template <int K4>     // dot of a K4*4-long row of `w` with the LDS vector `x`, lanes stride the float4s, wave-reduced
+__device__ __forceinline__ float wave_dot(const float *__restrict__ w, const float *x, int lane) {
+  float acc = 0.f;
+#pragma unroll
+  for (int k = lane; k < K4; k += 64) {
+    const float4 a = reinterpret_cast<const float4 *>(w)[k], v = reinterpret_cast<const float4 *>(x)[k];
+    acc += (a.x * v.x + a.y * v.y) + (a.z * v.z + a.w * v.w);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void head_select_kernel(HeadSel a) {
+  __shared__ float s_v[256];
+  __shared__ int s_i[256];
+  __shared__ __attribute__((aligned(16))) float s_x[384], s_h1[640], s_h2[256], s_h3[128];
+  __shared__ float s_y[4];
+  const int b = blockIdx.x, tower = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  long o = a.obj[b];
+  o = o < 0 ? 0 : (o >= a.num_obj ? a.num_obj - 1 : o);
+  // 1. confidence at every point, first maximum wins (torch.max; eval_ycb.py:196)
+  const f32x4 *wv = reinterpret_cast<const f32x4 *>(a.w_c + o * 128);
+  const float bv = a.b_c[o];
+  float best = -__builtin_inff();
+  int bi = 0x7fffffff;
+  for (int n = tid; n < a.N; n += 256) {
+    const f32x4 *xv = reinterpret_cast<const f32x4 *>(a.h3c + ((size_t)b * a.Npad + n) * 128);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const f32x4 x = xv[k], c = wv[k];
+      acc += (x[0] * c[0] + x[1] * c[1]) + (x[2] * c[2] + x[3] * c[3]);
+    }
+    acc += bv;
+    const float conf = 1.f / (1.f + expf(-acc));
+    if (conf > best) { best = conf; bi = n; }
+  }
+  s_v[tid] = best; s_i[tid] = bi;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (tid < d) {
+      const float ov = s_v[tid + d];
+      const int oi = s_i[tid + d];
+      if (ov > s_v[tid] || (ov == s_v[tid] && oi < s_i[tid])) { s_v[tid] = ov; s_i[tid] = oi; }
+    }
+    __syncthreads();
+  }
+  int wm = s_i[0];
+  if (wm < 0 || wm >= a.N) wm = 0;             // all-NaN confidences
+  const size_t row = (size_t)b * a.Npad + wm;
+  // 2. tower `tower` at the winning point
+  for (int k = tid; k < 384; k += 256) s_x[k] = a.pf[row * 384 + k];
+  __syncthreads();
+  for (int j = wave; j < 640; j += 4) {
+    const float v = wave_dot<96>(a.w1 + (size_t)(tower * 640 + j) * 384, s_x, lane) + a.gbias[(size_t)b * 1920 + tower * 640 + j];
+    if (lane == 0) s_h1[j] = fmaxf(v, 0.f);
+  }
+  __syncthreads();
+  for (int j = wave; j < 256; j += 4) {
+    const float v = wave_dot<160>(a.w2 + ((size_t)tower * 256 + j) * 640, s_h1, lane) + a.b2[tower * 256 + j];
+    if (lane == 0) s_h2[j] = fmaxf(v, 0.f);
+  }
+  __syncthreads();
+  for (int j = wave; j < 128; j += 4) {
+    const float v = wave_dot<64>(a.w3 + ((size_t)tower * 128 + j) * 256, s_h2, lane) + a.b3[tower * 128 + j];
+    if (lane == 0) s_h3[j] = fmaxf(v, 0.f);
+  }
+  __syncthreads();
+  const int nout = tower == 0 ? 4 : 3;
+  if (wave < nout) {
+    const float *w = tower == 0 ? a.w_r + (o * 4 + wave) * 128 : a.w_t + (o * 3 + wave) * 128;
+    const float v = wave_dot<32>(w, s_h3, lane) + (tower == 0 ? a.b_r[o * 4 + wave] : a.b_t[o * 3 + wave]);
+    if (lane == 0) s_y[wave] = v;
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  // 3. pose record (same arithmetic as pose_select_kernel)
+  if (tower == 0) {
+    const float nrm = sqrtf(s_y[0] * s_y[0] + s_y[1] * s_y[1] + s_y[2] * s_y[2] + s_y[3] * s_y[3]);
+    double q[4], M[9];
+    for (int e = 0; e < 4; ++e) {
+      q[e] = (double)(s_y[e] / nrm);
+      a.state[b * 7 + e] = q[e];
+      if (a.pose_wo) a.pose_wo[b * 7 + e] = q[e];
+    }
+    quat_to_mat(q, M);
+    for (int e = 0; e < 9; ++e) a.rt[b * 12 + e] = (float)M[e];
+    if (a.which) a.which[b] = wm;
+  } else {
+    for (int e = 0; e < 3; ++e) {
+      const double t = (double)(a.cloud[((size_t)b * a.N + wm) * 3 + e] + s_y[e]);
+      a.state[b * 7 + 4 + e] = t;
+      if (a.pose_wo) a.pose_wo[b * 7 + 4 + e] = t;
+      a.rt[b * 12 + 9 + e] = (float)t;
+    }
+  }
+}
+
 }  // namespace
 
 void launch_pose_select(const float *out_r, const float *out_t, const float *out_c, const float *cloud, int B, int N,
                         double *pose_wo, double *state, float *rt, int *which, hipStream_t st) {
   hipLaunchKernelGGL(pose_select_kernel, dim3(B), dim3(256), 0, st, out_r, out_t, out_c, cloud, N, pose_wo, state, rt, which);
+}
+
+void launch_head_select(const float *h3c, const float *w_c, const float *b_c, const float *pf, const float *gbias, const float *w1,
+                        const float *w2, const float *b2, const float *w3, const float *b3, const float *w_r, const float *b_r,
+                        const float *w_t, const float *b_t, const int64_t *obj, int num_obj, const float *cloud, int B, int N, int Npad,
+                        double *pose_wo, double *state, float *rt, int *which, hipStream_t st) {
+  HeadSel a;
+  a.h3c = h3c; a.w_c = w_c; a.b_c = b_c; a.pf = pf; a.gbias = gbias; a.w1 = w1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3;
+  a.w_r = w_r; a.b_r = b_r; a.w_t = w_t; a.b_t = b_t; a.obj = obj; a.cloud = cloud; a.num_obj = num_obj; a.N = N; a.Npad = Npad;
+  a.pose_wo = pose_wo; a.state = state; a.rt = rt; a.which = which;
+  hipLaunchKernelGGL(head_select_kernel, dim3(B, 2), dim3(256), 0, st, a);
 }
 
 void launch_refiner_tail(const float *f2, const float *w_r, const float *b_r, const float *w_t, const float *b_t,
