@@ -352,7 +352,7 @@ static void wino_conv(Ctx &c, const float *x, int B, int H, int W, int cin, int 
   ConvParams p = point_gemm(V, cin, 0, cin, c.w(wkey + ".wino"), nullptr, M, cout, 0, cout, (int)g.T, ACT_NONE);
   p.zcount = 16; p.z_in_coff = g.T * cin; p.z_wgt = (long)cout * cin; p.z_out_coff = g.T * cout;
   c.conv(p);
-  if (c.live()) launch_wino_output(M, out, out_ld, out_coff, res, res_ld, 0, act, B, H, W, cout, dil, c.st);
+  if (c.live()) launch_wino_output(M, out, out_ld, out_coff, nullptr, res, res_ld, 0, act, B, H, W, cout, dil, c.st);
   c.off = mark;
 }
 
@@ -819,6 +819,45 @@ extern "C" int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream) {
   if (p.OH != conv_out(p.H, p.KH, p.stride, p.pad, p.dil) || p.OW != conv_out(p.W, p.KW, p.stride, p.pad, p.dil))
     return set_error(DF_ERR_ARG, "conv2d_nhwc: OH/OW do not match the convolution geometry");
   return launch_conv(p, to_stream(stream));
+}
+
+// 3x3 stride-1 pad=dil convolution through the Winograd F(2x2,3x3) domain (wino.hip): weight transform, input
+// transform, 16 batched GEMMs, output transform (+ bias, residual, ReLU).  scratch holds U | V | M.
+static int wino_desc_ok(const df_conv_desc *d, const char *what) {
+  if (!d) return set_error(DF_ERR_ARG, "%s: null descriptor", what);
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != d->dil || d->dil < 1)
+    return set_error(DF_ERR_ARG, "%s: needs a 3x3 kernel, stride 1, pad == dil", what);
+  if (d->Cin % 4 || d->Cout % 4 || d->in_ld % 4 || d->in_coff % 4 || d->out_ld % 4 || d->out_coff % 4 || d->B <= 0 || d->H <= 0 || d->W <= 0)
+    return set_error(DF_ERR_ARG, "%s: channel counts / strides must be multiples of 4", what);
+  if (d->OH != d->H || d->OW != d->W) return set_error(DF_ERR_ARG, "%s: OH/OW must equal H/W", what);
+  if (d->act != ACT_NONE && d->act != ACT_RELU) return set_error(DF_ERR_ARG, "%s: activation must be none or ReLU", what);
+  return DF_OK;
+}
+
+extern "C" size_t df_conv3x3_winograd_scratch_bytes(const df_conv_desc *d) {
+  if (wino_desc_ok(d, "conv3x3_winograd_scratch_bytes") != DF_OK) return 0;
+  const WinoGeom g = wino_geom(d->B, d->H, d->W, d->dil);
+  return ((size_t)16 * d->Cout * d->Cin + (size_t)16 * g.T * d->Cin + (size_t)16 * g.T * d->Cout) * sizeof(float);
+}
+
+extern "C" int df_conv3x3_winograd_nhwc(const df_conv_desc *d, void *scratch, size_t scratch_bytes, df_stream_t stream) {
+  int rc = wino_desc_ok(d, "conv3x3_winograd_nhwc");
+  if (rc != DF_OK) return rc;
+  if (!d->in || !d->wgt || !d->out || !scratch) return set_error(DF_ERR_ARG, "conv3x3_winograd_nhwc: null pointer");
+  if (scratch_bytes < df_conv3x3_winograd_scratch_bytes(d)) return set_error(DF_ERR_WORKSPACE, "conv3x3_winograd_nhwc: scratch too small");
+  const WinoGeom g = wino_geom(d->B, d->H, d->W, d->dil);
+  hipStream_t st = to_stream(stream);
+  float *U = static_cast<float *>(scratch), *V = U + (size_t)16 * d->Cout * d->Cin, *M = V + (size_t)16 * g.T * d->Cin;
+  launch_wino_weight(d->wgt, U, d->Cout, d->Cin, st);
+  launch_wino_input(d->in, d->in_ld, d->in_coff, V, d->B, d->H, d->W, d->Cin, d->dil, st);
+  ConvParams p;
+  p.in = V; p.wgt = U; p.out = M;
+  p.B = (int)g.T; p.Cin = d->Cin; p.in_ld = d->Cin; p.Cout = d->Cout; p.out_ld = d->Cout;
+  p.zcount = 16; p.z_in_coff = g.T * d->Cin; p.z_wgt = (long)d->Cout * d->Cin; p.z_out_coff = g.T * d->Cout;
+  rc = launch_conv(p, st);
+  if (rc != DF_OK) return rc;
+  launch_wino_output(M, d->out, d->out_ld, d->out_coff, d->bias, d->res, d->res_ld, d->res_coff, d->act, d->B, d->H, d->W, d->Cout, d->dil, st);
+  return check_launch("conv3x3_winograd_nhwc");
 }
 
 // ------------------------------------------------------------------------------------------------

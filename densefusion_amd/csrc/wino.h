@@ -10,7 +10,7 @@ WinoGeom wino_geom(int B, int H, int W, int dil);
 bool wino_pays(int H, int W, int dil, int Cin, int Cout);
 void launch_wino_weight(const float *w_packed /*[O][3][3][C]*/, float *U /*[16][O][C]*/, int O, int C, hipStream_t st);
 void launch_wino_input(const float *x, int in_ld, int in_coff, float *V /*[16][T][C]*/, int B, int H, int W, int C, int dil, hipStream_t st);
-void launch_wino_output(const float *M /*[16][T][C]*/, float *out, int out_ld, int out_coff, const float *res, int res_ld, int res_coff,
-                        int act, int B, int H, int W, int C, int dil, hipStream_t st);
+void launch_wino_output(const float *M /*[16][T][C]*/, float *out, int out_ld, int out_coff, const float *bias, const float *res, int res_ld,
+                        int res_coff, int act, int B, int H, int W, int C, int dil, hipStream_t st);
 
 }  // namespace df

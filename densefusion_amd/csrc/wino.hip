@@ -102,9 +102,10 @@ __global__ __launch_bounds__(WB) void wino_input_kernel(const float *__restrict_
   }
 }
 
-// out = act( A^T M A + res ),  A^T = [[1,1,1,0],[0,1,-1,-1]];  one thread per (tile, 4 output channels)
+// out = act( A^T M A + bias + res ),  A^T = [[1,1,1,0],[0,1,-1,-1]];  one thread per (tile, 4 output channels)
 __global__ __launch_bounds__(WB) void wino_output_kernel(const float *__restrict__ Mz, float *__restrict__ out, int out_ld, int out_coff,
-                                                         const float *__restrict__ res, int res_ld, int res_coff, int act, int H, int W,
+                                                         const float *__restrict__ bias, const float *__restrict__ res, int res_ld,
+                                                         int res_coff, int act, int H, int W,
                                                          int C, int d, int TH, int TW, long T) {
   const int c4n = C >> 2;
   const long total = T * c4n;
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(WB) void wino_output_kernel(const float *__restrict
         if (xx >= W) continue;
         const size_t pix = (size_t)(id.b * H + yy) * W + xx;
         float4 v = y[a][b2];
+        if (bias) v = f4add(v, *reinterpret_cast<const float4 *>(bias + c));
         if (res) v = f4add(v, *reinterpret_cast<const float4 *>(res + pix * res_ld + res_coff + c));
         if (act == ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
         *reinterpret_cast<float4 *>(out + pix * out_ld + out_coff + c) = v;
@@ -179,11 +181,11 @@ void launch_wino_input(const float *x, int in_ld, int in_coff, float *V, int B, 
   hipLaunchKernelGGL(wino_input_kernel, dim3(blocks_for(g.T * (C / 4))), dim3(WB), 0, st, x, in_ld, in_coff, V, H, W, C, dil, g.TH, g.TW, g.T);
 }
 
-void launch_wino_output(const float *M, float *out, int out_ld, int out_coff, const float *res, int res_ld, int res_coff, int act, int B,
-                        int H, int W, int C, int dil, hipStream_t st) {
+void launch_wino_output(const float *M, float *out, int out_ld, int out_coff, const float *bias, const float *res, int res_ld, int res_coff,
+                        int act, int B, int H, int W, int C, int dil, hipStream_t st) {
   const WinoGeom g = wino_geom(B, H, W, dil);
-  hipLaunchKernelGGL(wino_output_kernel, dim3(blocks_for(g.T * (C / 4))), dim3(WB), 0, st, M, out, out_ld, out_coff, res, res_ld, res_coff,
-                     act, H, W, C, dil, g.TH, g.TW, g.T);
+  hipLaunchKernelGGL(wino_output_kernel, dim3(blocks_for(g.T * (C / 4))), dim3(WB), 0, st, M, out, out_ld, out_coff, bias, res, res_ld,
+                     res_coff, act, H, W, C, dil, g.TH, g.TW, g.T);
 }
 
 }  // namespace df

@@ -81,3 +81,28 @@ class ConvNHWC(torch.autograd.Function):
                 _lib.check(L.df_conv2d_wgrad_nhwc(ctypes.byref(d), dy.data_ptr(), dw.data_ptr(),
                                                   db.data_ptr() if db is not None else None, _lib.current_stream()), "conv2d_wgrad")
         return dx, dw, db, None, None, None
+
+
+def conv3x3_winograd_nhwc(x, w, bias=None, dil=1, act=0, res=None):
+    """3x3 / stride 1 / pad == dil convolution through the Winograd F(2x2,3x3) domain (``df_conv3x3_winograd_nhwc``).
+    x [B,H,W,Cin], w [Cout,3,3,Cin] -> [B,H,W,Cout]."""
+    B, H, W, in_ld = x.shape
+    Cout, KH, KW, Cin = w.shape
+    out = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.float32)
+    d = _lib.ConvDesc()
+    d.in_, d.wgt, d.out = _lib.dptr(x), _lib.dptr(w), _lib.dptr(out)
+    d.bias = _lib.dptr(bias) if bias is not None else None
+    d.res = _lib.dptr(res) if res is not None else None
+    d.prelu = None
+    d.B, d.H, d.W, d.Cin, d.in_ld, d.in_coff = B, H, W, Cin, in_ld, 0
+    d.OH, d.OW, d.Cout, d.out_ld, d.out_coff = H, W, Cout, Cout, 0
+    d.res_ld, d.res_coff = (res.shape[-1] if res is not None else 0), 0
+    d.KH, d.KW, d.stride, d.pad, d.dil, d.act = KH, KW, 1, dil, dil, act
+    L = _lib.lib()
+    with torch.cuda.device(x.device):
+        need = L.df_conv3x3_winograd_scratch_bytes(ctypes.byref(d))
+        if need == 0:
+            _lib.check(-1, "conv3x3_winograd_scratch_bytes")
+        scratch = torch.empty(int(need), dtype=torch.uint8, device=x.device)
+        _lib.check(L.df_conv3x3_winograd_nhwc(ctypes.byref(d), scratch.data_ptr(), need, _lib.current_stream()), "conv3x3_winograd_nhwc")
+    return out

@@ -193,6 +193,14 @@ typedef struct df_conv_desc {
   int32_t KH, KW, stride, pad, dil, act;
 } df_conv_desc;
 int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream);
+
+/* The same operator for 3x3 / stride 1 / pad == dil (any dilation) evaluated through the Winograd F(2x2,3x3) domain:
+ * 16 multiplies per 2x2 outputs instead of 36 (the path the engine takes for the 256/512-channel convs of the
+ * dilated ResNet trunk, lib/extractors.py:29-43,107-110).  Same descriptor; act none / ReLU; prelu unused.
+ * scratch (device) of df_conv3x3_winograd_scratch_bytes(d) holds the transformed weights and both transformed
+ * activations; results differ from df_conv2d_nhwc by fp32 re-association only. */
+size_t df_conv3x3_winograd_scratch_bytes(const df_conv_desc *d);
+int df_conv3x3_winograd_nhwc(const df_conv_desc *d, void *scratch, size_t scratch_bytes, df_stream_t stream);
 /* Gradients of df_conv2d_nhwc (training path; `d` describes the FORWARD convolution, d->wgt = its weights):
  *   dgrad: dx[b][iy][ix][in_coff + c] (+)= sum dy[b][oy][ox][out_coff + n] * wgt[n][ky][kx][c] over the taps/outputs that
  *          read that input pixel; runs on the same MFMA kernel as the forward pass on flipped, transposed weights

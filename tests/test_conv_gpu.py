@@ -80,3 +80,44 @@ def test_conv_argument_errors():
         conv2d_nhwc(torch.zeros(1, 4, 4, 6).cuda(), torch.zeros(8, 1, 1, 6).cuda())        # Cin % 4
     with pytest.raises(RuntimeError):
         conv2d_nhwc(torch.zeros(1, 4, 4, 12).cuda(), torch.zeros(8, 3, 3, 12).cuda(), pad=1)  # multi-tap non-pow2
+
+
+@pytest.mark.parametrize("geom", [
+    # (B, H, W, Cin, Cout, dil): trunk shapes (layer3 d1/d2, layer4 d1/d4), odd maps, maps shorter than one tile row
+    (2, 20, 20, 256, 256, 1), (2, 20, 20, 256, 256, 2), (1, 20, 20, 512, 512, 4), (2, 15, 20, 256, 512, 1),
+    (1, 15, 15, 64, 128, 4), (3, 7, 5, 32, 64, 2), (1, 30, 40, 128, 64, 4), (2, 3, 3, 16, 8, 1), (1, 2, 9, 8, 8, 4),
+])
+@pytest.mark.parametrize("fused", [False, True])
+def test_winograd_conv_matches_fp64(geom, fused):
+    """Winograd F(2x2,3x3) path vs an fp64 convolution; the direct kernel is measured beside it: the transform-domain
+    result may carry a few times the direct kernel's rounding error, no more."""
+    from densefusion_amd import ops
+    import torch.nn.functional as F
+    B, H, W, Cin, Cout, dil = geom
+    dev = torch.device("cuda:0")
+    torch.manual_seed(sum(geom))
+    x = (torch.relu(torch.randn(B, H, W, Cin)) * 3).to(dev)
+    w = (torch.randn(Cout, 3, 3, Cin) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
+    bias = torch.randn(Cout, device=dev) if fused else None
+    res = torch.randn(B, H, W, Cout, device=dev) if fused else None
+    act = 1 if fused else 0
+    want = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), bias.double() if fused else None, 1, dil, dil)
+    want = want.permute(0, 2, 3, 1)
+    if fused:
+        want = torch.relu(want + res.double())
+    got_w = ops.conv3x3_winograd_nhwc(x, w, bias, dil=dil, act=act, res=res)
+    got_d = ops.conv2d_nhwc(x, w, bias, stride=1, pad=dil, dil=dil, act=act, res=res)
+    scale = float(want.abs().max())
+    err_w = float((got_w.double() - want).abs().max()) / scale
+    err_d = float((got_d.double() - want).abs().max()) / scale
+    assert err_w < 3e-6, (err_w, err_d)
+    assert err_w < 8 * err_d + 1e-7, (err_w, err_d)
+
+
+def test_winograd_rejects_other_geometries():
+    from densefusion_amd import ops
+    dev = torch.device("cuda:0")
+    x = torch.randn(1, 8, 8, 8, device=dev)
+    w5 = torch.randn(8, 5, 5, 8, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_winograd_nhwc(x, w5)
