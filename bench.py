@@ -249,7 +249,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--per-bucket", type=int, default=20, help="objects of each crop size per step and GPU")
+    ap.add_argument("--per-bucket", type=int, default=40, help="objects of each crop size per step and GPU")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-streams", action="store_true", help="run the crop-size buckets back to back on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
