@@ -117,7 +117,9 @@ def measured_traffic():
     try:
         with open(os.path.join(ROOT, "profiles", "r01_igemm_traffic.json")) as f:
             t = json.load(f)
-        return {"hbm_mb_per_launch": round(t["avg_hbm_bytes_per_launch"] / 1e6, 2), "source": "profiles/r01_igemm_traffic.json (rocprofv3 --pmc, serial un-graphed run)"}
+        per = t["hbm_bytes_corrected_per_dispatch"]["total"] if "hbm_bytes_corrected_per_dispatch" in t else t["avg_hbm_bytes_per_launch"]
+        return {"hbm_mb_per_launch": round(per / 1e6, 2), "source": "profiles/r01_igemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                "separate passes, serial un-graphed run of this workload; tools/make_profiles.sh)"}
     except Exception:   # noqa: BLE001
         return None
 

@@ -390,74 +390,6 @@ __global__ __launch_bounds__(TPB) void colsum_finish_kernel(const float *__restr
   }
 }
 
-// y[r][col] = act(w[col] . x[r] + bias[col]) for a handful of rows (one per object) and wide weight matrices: the
-// time is the weight read.  A workgroup stages up to LR_ROWS input rows in LDS once (per tower group), every wave
-// then streams LR_COLS weight rows from HBM/L2 exactly once and keeps all row accumulators in registers.
-constexpr int LR_ROWS = 24, LR_COLS = 2;
-
-__global__ __launch_bounds__(TPB) void linear_rows_kernel(const float *__restrict__ x, int x_ld, int x_gstride,
-                                                          const float *__restrict__ w, const float *__restrict__ bias,
-                                                          float *__restrict__ y, int y_ld, int rows, int K, int nout,
-                                                          int groups, int relu) {
-  extern __shared__ __attribute__((aligned(16))) float s_x[];      // [LR_ROWS][K]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int CPB = (TPB / 64) * LR_COLS;                        // columns per workgroup
-  const int col0 = blockIdx.x * CPB;                               // nout % CPB == 0 is not required: groups never straddle
-  const int g = col0 / nout;                                       // (launcher keeps CPB | nout)
-  const int K4 = K >> 2;
-  for (int r0 = 0; r0 < rows; r0 += LR_ROWS) {
-    const int nr = min(LR_ROWS, rows - r0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < nr * K4; i += TPB) {
-      const int r = i / K4, k4 = i - r * K4;
-      reinterpret_cast<f32x4 *>(s_x)[r * K4 + k4] = *reinterpret_cast<const f32x4 *>(x + (size_t)(r0 + r) * x_ld + g * x_gstride + k4 * 4);
-    }
-    __syncthreads();
-    float acc[LR_COLS][LR_ROWS];
-#pragma unroll
-    for (int c = 0; c < LR_COLS; ++c)
-#pragma unroll
-      for (int r = 0; r < LR_ROWS; ++r) acc[c][r] = 0.f;
-    const int colw = col0 + wave * LR_COLS;
-    for (int k4 = lane; k4 < K4; k4 += 64) {
-      f32x4 wv[LR_COLS];
-#pragma unroll
-      for (int c = 0; c < LR_COLS; ++c)
-        wv[c] = colw + c < nout * groups ? reinterpret_cast<const f32x4 *>(w + (size_t)(colw + c) * K)[k4] : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < LR_ROWS; ++r) {
-        if (r < nr) {
-          const f32x4 xv = reinterpret_cast<const f32x4 *>(s_x)[r * K4 + k4];
-#pragma unroll
-          for (int c = 0; c < LR_COLS; ++c) acc[c][r] += (wv[c][0] * xv[0] + wv[c][1] * xv[1]) + (wv[c][2] * xv[2] + wv[c][3] * xv[3]);
-        }
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < LR_COLS; ++c)
-#pragma unroll
-      for (int r = 0; r < LR_ROWS; ++r) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) acc[c][r] += __shfl_xor(acc[c][r], d);
-      }
-    if (lane == 0) {
-#pragma unroll
-      for (int c = 0; c < LR_COLS; ++c) {
-        const int col = colw + c;
-        if (col >= nout * groups) continue;
-        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < LR_ROWS; ++r)
-          if (r < nr) {
-            float v = acc[c][r] + bv;
-            if (relu) v = v > 0.f ? v : 0.f;
-            y[(size_t)(r0 + r) * y_ld + col] = v;
-          }
-      }
-    }
-  }
-}
-
 // thread = (point, output j): j 0-3 quaternion, 4-6 translation, 7 confidence (sigmoid)
 __global__ __launch_bounds__(TPB) void head_final_kernel(const float *__restrict__ h3, const float *__restrict__ w_r,
                                                          const float *__restrict__ b_r, const float *__restrict__ w_t,
@@ -541,18 +473,6 @@ void launch_cloud_conv1(const float *cloud, const float *rt, const float *w, con
 void launch_colsum_finish(const float *partial, int rows_per_obj, float *mean, int B, int C, int N, hipStream_t st) {
   hipLaunchKernelGGL(colsum_finish_kernel, dim3(blocks_for((long)B * C)), dim3(TPB), 0, st, partial, rows_per_obj, mean,
                      B, C, N);
-}
-void launch_linear_rows(const float *x, int x_ld, int x_gstride, const float *w, const float *bias, float *y, int y_ld,
-                        int rows, int K, int nout, int groups, int relu, hipStream_t st) {
-  constexpr int CPB = (TPB / 64) * LR_COLS;
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LR_ROWS * 1024 * 4);
-    attr = true;
-  }
-  // a workgroup's CPB columns share one tower group's input slice: nout must be a multiple of CPB (it is 128 .. 1920 here)
-  hipLaunchKernelGGL(linear_rows_kernel, dim3((nout * groups + CPB - 1) / CPB), dim3(TPB), (size_t)LR_ROWS * K * sizeof(float), st, x, x_ld,
-                     x_gstride, w, bias, y, y_ld, rows, K, nout, groups, relu);
 }
 void launch_head_final(const float *h3, const float *w_r, const float *b_r, const float *w_t, const float *b_t,
                        const float *w_c, const float *b_c, const int64_t *obj, int num_obj, float *out_r, float *out_t,

@@ -14,7 +14,7 @@ void launch_pose_select(const float *out_r, const float *out_t, const float *out
 void launch_head_select(const float *h3c, const float *w_c, const float *b_c, const float *pf, const float *gbias, const float *w1,
                         const float *w2, const float *b2, const float *w3, const float *b3, const float *w_r, const float *b_r,
                         const float *w_t, const float *b_t, const int64_t *obj, int num_obj, const float *cloud, int B, int N, int Npad,
-                        double *pose_wo, double *state, float *rt, int *which, hipStream_t st);
+                        float *conf /*[B][N] scratch*/, double *pose_wo, double *state, float *rt, int *which, hipStream_t st);
 
 // per object: refiner conv3_r/conv3_t rows of the selected object on f2 [B][256] (r|t towers), raw outputs to
 // out_r[B][4] / out_t[B][3] when non-null; when state != null also compose into state and refresh rt

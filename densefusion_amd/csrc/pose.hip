@@ -158,14 +158,13 @@ __global__ __launch_bounds__(64) void refiner_tail_kernel(const float *__restric
 // ---- confidence-first head evaluation (eval loop only) -------------------------------------------------------------
 // tools/eval_ycb.py:193-203 uses pred_r / pred_t at ONE pixel per object -- the arg-max of the confidence -- so the
 // r and t towers (lib/network.py:107-121) need evaluating at that pixel only.  The engine runs the confidence tower
-// for all N points as GEMMs; this kernel finishes the job: conv4_c + sigmoid + arg-max over the N points (the same
-// expression and summation order as head_final_kernel, so the same winner as the full forward), then conv1..conv4 of
-// tower blockIdx.y (0 = r, 1 = t) for the winning point as wave-per-output dot products, then the pose record.
+// for all N points as GEMMs; head_conf_kernel adds conv4_c + sigmoid, and head_select_kernel finishes the job: arg-max
+// over the N points, then conv1..conv4 of tower blockIdx.y (0 = r, 1 = t) for the winning point as wave-per-output dot
+// products, then the pose record.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct HeadSel {
-  const float *h3c;                       // [rows][128] confidence-tower features
-  const float *w_c, *b_c;                 // conv4_c [K][128], [K]
+  const float *conf;                      // [B][N] confidences (head_conf_kernel)
   const float *pf;                        // [rows][384] pointfeat_1 | pointfeat_2
   const float *gbias;                     // [B][1920] global-feature part of head layer 1 (+ bias), towers r|t|c
   const float *w1;                        // [1920][384] per-point part of head layer 1
@@ -193,6 +192,29 @@ __device__ __forceinline__ float wave_dot(const float *__restrict__ w, const flo
   return acc;
 }
 
+// confidence of every point: thread = point, conv4_c row of the object + sigmoid -- the expression and summation order of
+// head_final_kernel (layers.hip), so the full forward and the eval loop see the same values and pick the same point
+__global__ __launch_bounds__(256) void head_conf_kernel(const float *__restrict__ h3c, const float *__restrict__ w_c,
+                                                        const float *__restrict__ b_c, const int64_t *__restrict__ obj, int num_obj,
+                                                        float *__restrict__ conf, int B, int N, int Npad) {
+  const long total = (long)B * N;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < total; p += (long)gridDim.x * 256) {
+    const long b = p / N, n = p - b * N;
+    long o = obj[b];
+    o = o < 0 ? 0 : (o >= num_obj ? num_obj - 1 : o);
+    const f32x4 *wv = reinterpret_cast<const f32x4 *>(w_c + o * 128);
+    const f32x4 *xv = reinterpret_cast<const f32x4 *>(h3c + ((size_t)b * Npad + n) * 128);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const f32x4 x = xv[k], c = wv[k];
+      acc += (x[0] * c[0] + x[1] * c[1]) + (x[2] * c[2] + x[3] * c[3]);
+    }
+    acc += b_c[o];
+    conf[p] = 1.f / (1.f + expf(-acc));
+  }
+}
+
 __global__ __launch_bounds__(256) void head_select_kernel(HeadSel a) {
   __shared__ float s_v[256];
   __shared__ int s_i[256];
@@ -201,21 +223,11 @@ __global__ __launch_bounds__(256) void head_select_kernel(HeadSel a) {
   const int b = blockIdx.x, tower = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   long o = a.obj[b];
   o = o < 0 ? 0 : (o >= a.num_obj ? a.num_obj - 1 : o);
-  // 1. confidence at every point, first maximum wins (torch.max; eval_ycb.py:196)
-  const f32x4 *wv = reinterpret_cast<const f32x4 *>(a.w_c + o * 128);
-  const float bv = a.b_c[o];
+  // 1. first maximum of the confidences wins (torch.max; eval_ycb.py:196)
   float best = -__builtin_inff();
   int bi = 0x7fffffff;
   for (int n = tid; n < a.N; n += 256) {
-    const f32x4 *xv = reinterpret_cast<const f32x4 *>(a.h3c + ((size_t)b * a.Npad + n) * 128);
-    float acc = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < 32; ++k) {
-      const f32x4 x = xv[k], c = wv[k];
-      acc += (x[0] * c[0] + x[1] * c[1]) + (x[2] * c[2] + x[3] * c[3]);
-    }
-    acc += bv;
-    const float conf = 1.f / (1.f + expf(-acc));
+    const float conf = a.conf[(size_t)b * a.N + n];
     if (conf > best) { best = conf; bi = n; }
   }
   s_v[tid] = best; s_i[tid] = bi;
@@ -289,9 +301,11 @@ void launch_pose_select(const float *out_r, const float *out_t, const float *out
 void launch_head_select(const float *h3c, const float *w_c, const float *b_c, const float *pf, const float *gbias, const float *w1,
                         const float *w2, const float *b2, const float *w3, const float *b3, const float *w_r, const float *b_r,
                         const float *w_t, const float *b_t, const int64_t *obj, int num_obj, const float *cloud, int B, int N, int Npad,
-                        double *pose_wo, double *state, float *rt, int *which, hipStream_t st) {
+                        float *conf, double *pose_wo, double *state, float *rt, int *which, hipStream_t st) {
+  const long pts = (long)B * N;
+  hipLaunchKernelGGL(head_conf_kernel, dim3((unsigned)((pts + 255) / 256)), dim3(256), 0, st, h3c, w_c, b_c, obj, num_obj, conf, B, N, Npad);
   HeadSel a;
-  a.h3c = h3c; a.w_c = w_c; a.b_c = b_c; a.pf = pf; a.gbias = gbias; a.w1 = w1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3;
+  a.conf = conf; a.pf = pf; a.gbias = gbias; a.w1 = w1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3;
   a.w_r = w_r; a.b_r = b_r; a.w_t = w_t; a.b_t = b_t; a.obj = obj; a.cloud = cloud; a.num_obj = num_obj; a.N = N; a.Npad = Npad;
   a.pose_wo = pose_wo; a.state = state; a.rt = rt; a.which = which;
   hipLaunchKernelGGL(head_select_kernel, dim3(B, 2), dim3(256), 0, st, a);
