@@ -455,23 +455,23 @@ static float *cnn_forward(Ctx &c, int B, int H, int W, const float *img, int &ou
     p.res = prior; p.res_ld = 1024;
     c.conv(p);
   }
-  // three PSPUpsample stages (lib/pspnet.py:27-37,69-75; dropout = identity in eval), each as a low-resolution
-  // GEMM with N = 9*Cout followed by the 9-tap interpolation (layers.hip).  The last stage's interpolation is
-  // done only at the chosen pixels, inside the gather kernel, so the full-resolution map is never formed.
+  // PSPUpsample stages up_1, up_2 (lib/pspnet.py:27-37,69-73; dropout = identity in eval), each as a low-resolution
+  // GEMM with N = 9*Cout followed by the 9-tap interpolation (layers.hip).  up_3 is NOT run here: its output is read
+  // at the chosen pixels only, so the caller evaluates it there (posenet_forward) from the map returned: [B][h][w][64].
   float *cur = psp;
-  const char *ups[3] = {"up_1", "up_2", "up_3"};
-  const int up_in[3] = {1024, 256, 64}, up_out[3] = {256, 64, 64};
-  for (int u = 0; u < 3; ++u) {
+  const char *ups[2] = {"up_1", "up_2"};
+  const int up_in[2] = {1024, 256}, up_out[2] = {256, 64};
+  for (int u = 0; u < 2; ++u) {
     float *y = c.f((size_t)B * h * w * 9 * up_out[u]);
     c.conv(point_gemm(cur, up_in[u], 0, up_in[u], c.w(P + ups[u] + ".conv.1.weight.tm"), nullptr, y, 9 * up_out[u], 0, 9 * up_out[u],
                       B * h * w, ACT_NONE));
-    if (u == 2) { outH = h; outW = w; return y; }      // y3 [B][h][w][576]; consumer interpolates at chosen pixels
     float *o = c.f((size_t)B * 4 * h * w * up_out[u]);
     if (c.live())
       launch_upconv_gather(y, c.w(P + ups[u] + ".conv.1.bias"), c.w(P + ups[u] + ".conv.2.weight"), o, B, h, w, up_out[u], c.st);
     h *= 2; w *= 2;
     cur = o;
   }
+  outH = h; outW = w;
   return cur;
 }
 
@@ -548,12 +548,19 @@ static void posenet_forward(Ctx &c, int B, int H, int W, const float *img, const
                             const int64_t *obj, PoseNetOut &o, const SelectOut *sel = nullptr) {
   const int N = c.net->num_points, Npad = round_up(N, 128);
   int fh = 0, fw = 0;
-  float *y3 = cnn_forward(c, B, H, W, img, fh, fw);      // fh x fw = the half-resolution grid of up_3's input
+  float *half = cnn_forward(c, B, H, W, img, fh, fw);     // up_2's output, fh x fw = half resolution, 64 channels
+  // up_3 (bilinear x2 + conv3x3 + PReLU) at the chosen pixels: patch rows, one GEMM with the PReLU fused, then the
+  // final 1x1 conv + LogSoftmax
+  const std::string P = CNN;
+  float *patch = c.f((size_t)B * Npad * 576), *z3 = c.f((size_t)B * Npad * 64);
+  if (c.live()) launch_up3_patches(half, choose, patch, B, fh, fw, N, Npad, c.st);
+  {
+    ConvParams p = point_gemm(patch, 576, 0, 576, c.w(P + "up_3.conv.1.weight"), c.w(P + "up_3.conv.1.bias"), z3, 64, 0, 64, B * Npad, ACT_PRELU);
+    p.prelu = c.w(P + "up_3.conv.2.weight");
+    c.conv(p);
+  }
   o.emb_pm = c.f((size_t)B * Npad * 32);
-  if (c.live())
-    launch_gather_final_logsoftmax(y3, c.w(std::string(CNN) + "up_3.conv.1.bias"), c.w(std::string(CNN) + "up_3.conv.2.weight"), choose,
-                                   c.w(std::string(CNN) + "final.0.weight"), c.w(std::string(CNN) + "final.0.bias"), o.emb,
-                                   o.emb_pm, B, fh, fw, N, Npad, c.st);
+  if (c.live()) launch_final_logsoftmax(z3, c.w(P + "final.0.weight"), c.w(P + "final.0.bias"), o.emb, o.emb_pm, B, N, Npad, c.st);
   posenet_points(c, B, N, Npad, cloud, o.emb_pm, obj, o.out_r, o.out_t, o.out_c, sel);
 }
 

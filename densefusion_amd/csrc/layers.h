@@ -22,12 +22,14 @@ void launch_transpose2d(const float *in, float *out, int R, int C, hipStream_t s
 void launch_upconv_gather(const float *y, const float *bias, const float *prelu, float *out, int B, int h, int w, int Cout,
                           hipStream_t st);
 void launch_tapmajor(const float *src, float *dst, int O, int I, hipStream_t st);   // [O][9][I] -> [9][O][I]
-// up_3 (same interpolation, 64 channels) + final 1x1 conv 64->32 + LogSoftmax over channels (lib/pspnet.py:53-56)
-// evaluated ONLY at the N chosen pixels (lib/network.py:98-102).  y3 [B][h][w][576]; choose [B][N] int64 indexes
-// the (2h x 2w) map; emb [B][32][N] (reference layout) and emb_pm [B][Npad][32] (point-major, for the MLPs)
-void launch_gather_final_logsoftmax(const float *y3, const float *bias3, const float *prelu3, const int64_t *choose,
-                                    const float *w, const float *bias, float *emb, float *emb_pm, int B, int h, int wd, int N,
-                                    int Npad, hipStream_t st);
+// up_3 only at the N chosen pixels (lib/network.py:98-102): per chosen pixel the 3x3 patch of the bilinearly upsampled
+// (align_corners) half-resolution map x [B][h][w][64], as GEMM rows patch [B*Npad][9*64] (zero rows for n >= N);
+// choose [B][N] int64 indexes the (2h x 2w) map
+void launch_up3_patches(const float *x, const int64_t *choose, float *patch, int B, int h, int wd, int N, int Npad, hipStream_t st);
+// final 1x1 conv 64->32 + LogSoftmax over channels (lib/pspnet.py:53-56) on rows z [B*Npad][64] ->
+// emb [B][32][N] (reference layout) and emb_pm [B][Npad][32] (point-major, for the MLPs)
+void launch_final_logsoftmax(const float *z, const float *w, const float *bias, float *emb, float *emb_pm, int B, int N, int Npad,
+                             hipStream_t st);
 // emb [B][32][N] -> emb_pm [B][Npad][32]  (PoseRefineNet.forward called on its own)
 void launch_emb_to_pm(const float *emb, float *emb_pm, int B, int N, int Npad, hipStream_t st);
 // Conv1d(3,64,1)+ReLU on the cloud (lib/network.py:54,152); optional rigid pre-transform
