@@ -250,6 +250,18 @@ static int load_param(Net &n, const std::string &key, const float *src, int64_t 
     if (!dst) return set_error(DF_ERR_LAUNCH, "load_param: hipMalloc failed");
     e = copy(dst, src, (size_t)numel);
   }
+  if (e == hipSuccess && n.kind == 1 && key == "feat.conv5.weight") {
+    // PoseRefineNetFeat.conv5 reads [x1 | e1 | x2 | e2] (lib/network.py:160-163); the colour half (e1, e2) does not change
+    // between refine iterations, so its product is formed once per object: split the columns into an xyz part
+    // [512][x1 64 | x2 128] and a colour part [512][e1 64 | e2 128] (the engine keeps the point features in that order)
+    const float *w5 = n.buf[key];
+    float *wx = dev_alloc(n, "feat.conv5.wx", (size_t)512 * 192), *we = dev_alloc(n, "feat.conv5.we", (size_t)512 * 192);
+    if (!wx || !we) return set_error(DF_ERR_LAUNCH, "load_param: hipMalloc failed");
+    e = copy2d(wx, 192, w5, 384, 64, 512);
+    if (e == hipSuccess) e = copy2d(wx + 64, 192, w5 + 128, 384, 128, 512);
+    if (e == hipSuccess) e = copy2d(we, 192, w5 + 64, 384, 64, 512);
+    if (e == hipSuccess) e = copy2d(we + 64, 192, w5 + 256, 384, 128, 512);
+  }
   if (e != hipSuccess) return set_error(DF_ERR_LAUNCH, "load_param(%s): %s", key.c_str(), hipGetErrorString(e));
   n.loaded[it->second] = 1;
   if (n.kind == 0 && key.find(".psp.") != std::string::npos && !ends_with(key, ".bias")) {
@@ -566,12 +578,13 @@ static void posenet_forward(Ctx &c, int B, int H, int W, const float *img, const
 
 // PoseRefineNetFeat + FC towers (lib/network.py:151-168,187-204).  The emb branch (e_conv1/e_conv2) does
 // not depend on the cloud, so `prepare` runs it once per object and `iterate` re-does only the xyz branch.
-struct RefinerBufs { float *pf, *x5, *partial, *apx, *f1, *f2; int prow; };
+struct RefinerBufs { float *pf, *e5, *x5, *partial, *apx, *f1, *f2; int prow; };   // pf rows: [x1 64 | x2 128 | e1 64 | e2 128]
 
 static RefinerBufs refiner_alloc(Ctx &c, int B, int N, int Npad) {
   RefinerBufs r;
   const int rows = B * Npad;
   r.pf = c.f((size_t)rows * 384);
+  r.e5 = c.f((size_t)rows * 512);
   r.x5 = c.f((size_t)rows * 512);
   ConvParams p6 = point_gemm(r.x5, 512, 0, 512, nullptr, nullptr, nullptr, 1024, 0, 1024, rows, ACT_RELU);
   p6.rows_per_group = Npad; p6.rows_valid = N;
@@ -585,16 +598,22 @@ static RefinerBufs refiner_alloc(Ctx &c, int B, int N, int Npad) {
 
 static void refiner_prepare(Ctx &c, const RefinerBufs &r, int B, int Npad, const float *emb_pm) {
   const int rows = B * Npad;
-  c.conv(point_gemm(emb_pm, 32, 0, 32, c.w("feat.e_conv1.weight"), c.w("feat.e_conv1.bias"), r.pf, 384, 64, 64, rows, ACT_RELU));
-  c.conv(point_gemm(r.pf, 384, 64, 64, c.w("feat.e_conv2.weight"), c.w("feat.e_conv2.bias"), r.pf, 384, 256, 128, rows, ACT_RELU));
+  c.conv(point_gemm(emb_pm, 32, 0, 32, c.w("feat.e_conv1.weight"), c.w("feat.e_conv1.bias"), r.pf, 384, 192, 64, rows, ACT_RELU));
+  c.conv(point_gemm(r.pf, 384, 192, 64, c.w("feat.e_conv2.weight"), c.w("feat.e_conv2.bias"), r.pf, 384, 256, 128, rows, ACT_RELU));
+  // colour half of conv5 (+ its bias), once per object; the iterations add the xyz half and apply the ReLU
+  c.conv(point_gemm(r.pf, 384, 192, 192, c.w("feat.conv5.we"), c.w("feat.conv5.bias"), r.e5, 512, 0, 512, rows, ACT_NONE));
 }
 
 static void refiner_iterate(Ctx &c, const RefinerBufs &r, int B, int N, int Npad, const float *cloud, const float *rt,
                             const int64_t *obj, float *out_r, float *out_t, double *state, float *rt_next, double *pose_out) {
   const int rows = B * Npad;
   if (c.live()) launch_cloud_conv1(cloud, rt, c.w("feat.conv1.weight"), c.w("feat.conv1.bias"), r.pf, 384, B, N, Npad, c.st);
-  c.conv(point_gemm(r.pf, 384, 0, 64, c.w("feat.conv2.weight"), c.w("feat.conv2.bias"), r.pf, 384, 128, 128, rows, ACT_RELU));
-  c.conv(point_gemm(r.pf, 384, 0, 384, c.w("feat.conv5.weight"), c.w("feat.conv5.bias"), r.x5, 512, 0, 512, rows, ACT_RELU));
+  c.conv(point_gemm(r.pf, 384, 0, 64, c.w("feat.conv2.weight"), c.w("feat.conv2.bias"), r.pf, 384, 64, 128, rows, ACT_RELU));
+  {
+    ConvParams p = point_gemm(r.pf, 384, 0, 192, c.w("feat.conv5.wx"), nullptr, r.x5, 512, 0, 512, rows, ACT_RELU);
+    p.res = r.e5; p.res_ld = 512;
+    c.conv(p);
+  }
   ConvParams p6 = point_gemm(r.x5, 512, 0, 512, c.w("feat.conv6.weight"), c.w("feat.conv6.bias"), nullptr, 1024, 0, 1024, rows, ACT_RELU);
   p6.rows_per_group = Npad; p6.rows_valid = N; p6.colsum = r.partial;
   c.conv(p6);

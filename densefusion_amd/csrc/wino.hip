@@ -165,11 +165,11 @@ WinoGeom wino_geom(int B, int H, int W, int dil) {
 
 bool wino_pays(int H, int W, int dil, int Cin, int Cout) {
   // per output map: 16 multiplies per tile against 9 per pixel, and the transforms move ~10 activation-sized tensors;
-  // take it only when the multiply count drops by a third or more, on channel counts whose GEMM (K = Cin) is deep enough.
+  // take it only when the multiply count drops by more than a quarter, on channel counts whose GEMM (K = Cin) is deep enough.
   // Depends on the layer geometry only -- never on the batch -- so batched and solo calls take the same path.
   if (Cin < 256 || Cin % 4 || Cout % 4) return false;
   const WinoGeom g = wino_geom(1, H, W, dil);
-  return 16.0 * (double)g.T <= 0.67 * 9.0 * (double)H * W;
+  return 16.0 * (double)g.T <= 0.72 * 9.0 * (double)H * W;
 }
 
 void launch_wino_weight(const float *w_packed, float *U, int O, int C, hipStream_t st) {
