@@ -92,8 +92,33 @@ def check(status: int, what: str = "") -> None:
 
 
 def current_stream() -> int:
+    """Raw hipStream_t of torch's current stream on the current device."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+    except AttributeError:                      # older / newer torch without the private accessor
+        return torch.cuda.current_stream().cuda_stream
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(device):
+    """``torch.cuda.device(device)`` only when `device` is not already current (the common single-GPU-per-process case
+    costs nothing)."""
+    import torch
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
 
 
 def dptr(t) -> int:

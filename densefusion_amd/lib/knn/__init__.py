@@ -28,7 +28,7 @@ class KNearestNeighbor:
         B, D, R = ref.shape
         Q = query.shape[2]
         inds = torch.empty(B, self.k, Q, dtype=torch.int64, device=query.device)
-        with torch.cuda.device(query.device):
+        with _lib.device_guard(query.device):
             st = _lib.lib().df_knn(_lib.dptr(ref), _lib.dptr(query), _lib.dptr(inds), B, D, R, Q, self.k,
                                    _lib.current_stream())
         _lib.check(st, "knn")

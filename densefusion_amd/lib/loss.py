@@ -35,7 +35,7 @@ class _LossFn(torch.autograd.Function):
         new_points, new_target = torch.empty(1, N, 3, device=dev), torch.empty(1, M, 3, device=dev)
         scratch = torch.empty(N, device=dev)
         sel = torch.empty(N, M, dtype=torch.int32, device=dev) if sym else None
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             st = _lib.lib().df_loss_forward(pr.data_ptr(), pt.data_ptr(), pc.data_ptr(), tg.data_ptr(), mp.data_ptr(),
                                             pts.data_ptr(), N, M, float(w), int(sym), loss.data_ptr(), dis.data_ptr(),
                                             new_points.data_ptr(), new_target.data_ptr(), scratch.data_ptr(),
@@ -51,7 +51,7 @@ class _LossFn(torch.autograd.Function):
         pr, pt, pc, tg, mp, pts, dis, sel = ctx.saved_tensors
         N, M, w, sym = ctx.meta
         d_r, d_t, d_c = torch.empty_like(pr), torch.empty_like(pt), torch.empty_like(pc)
-        with torch.cuda.device(pr.device):
+        with _lib.device_guard(pr.device):
             st = _lib.lib().df_loss_backward(pr.data_ptr(), pt.data_ptr(), pc.data_ptr(), tg.data_ptr(), mp.data_ptr(),
                                              pts.data_ptr(), sel.data_ptr() if sym else None, dis.data_ptr(), N, M, w,
                                              float(g_loss), d_r.data_ptr(), d_t.data_ptr(), d_c.data_ptr(), _lib.current_stream())

@@ -21,7 +21,7 @@ class _LossRefineFn(torch.autograd.Function):
         dis = torch.empty(1, device=dev)
         new_points, new_target = torch.empty(1, N, 3, device=dev), torch.empty(1, M, 3, device=dev)
         sel = torch.empty(M, dtype=torch.int32, device=dev) if sym else None
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             st = _lib.lib().df_loss_refine_forward(pr.data_ptr(), pt.data_ptr(), tg.data_ptr(), mp.data_ptr(), pts.data_ptr(), N, M,
                                                    int(sym), dis.data_ptr(), new_points.data_ptr(), new_target.data_ptr(),
                                                    sel.data_ptr() if sel is not None else None, _lib.current_stream())
@@ -36,7 +36,7 @@ class _LossRefineFn(torch.autograd.Function):
         pr, pt, tg, mp, sel = ctx.saved_tensors
         M, sym, shp_r, shp_t = ctx.meta
         d_r, d_t = torch.empty_like(pr), torch.empty_like(pt)
-        with torch.cuda.device(pr.device):
+        with _lib.device_guard(pr.device):
             st = _lib.lib().df_loss_refine_backward(pr.data_ptr(), pt.data_ptr(), tg.data_ptr(), mp.data_ptr(),
                                                     sel.data_ptr() if sym else None, M, float(g_dis.reshape(-1)[0]),
                                                     d_r.data_ptr(), d_t.data_ptr(), _lib.current_stream())

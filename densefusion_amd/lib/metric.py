@@ -18,7 +18,7 @@ def add_metric(pose, model_points, target, symmetric=None):
     sym = None
     if symmetric is not None:
         sym = torch.as_tensor(symmetric).to(device=pose.device, dtype=torch.int32).contiguous()
-    with torch.cuda.device(pose.device):
+    with _lib.device_guard(pose.device):
         st = _lib.lib().df_add_metric(pose.data_ptr(), mp.data_ptr(), tg.data_ptr(), sym.data_ptr() if sym is not None else None,
                                       B, M, out.data_ptr(), _lib.current_stream())
     _lib.check(st, "add_metric")

@@ -65,7 +65,7 @@ class _EngineModule(nn.Module):
         L = _lib.lib()
         if self._handle is None or self._handle_dev != device:
             self._release()
-            with torch.cuda.device(device):
+            with _lib.device_guard(device):
                 create = L.df_posenet_create if self._kind == "posenet" else L.df_refiner_create
                 self._handle = create(self.num_points, self.num_obj)
             if not self._handle:
@@ -139,7 +139,7 @@ class PoseNet(_EngineModule):
         out_c = torch.empty(B, N, 1, device=dev)
         emb = torch.empty(B, 32, N, device=dev)
         L = _lib.lib()
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             h = self._engine(dev)
             need = L.df_posenet_workspace_bytes(h, B, H, W)
             if need == 0:
@@ -173,7 +173,7 @@ class PoseRefineNet(_EngineModule):
         out_r = torch.empty(B, 4, device=dev)
         out_t = torch.empty(B, 3, device=dev)
         L = _lib.lib()
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             h = self._engine(dev)
             need = L.df_refiner_workspace_bytes(h, B)
             ws = self._workspace(need, dev)
@@ -197,7 +197,7 @@ class PoseEstimator:
 
     def workspace_bytes(self, B, H, W, device):
         L = _lib.lib()
-        with torch.cuda.device(device):
+        with _lib.device_guard(device):
             return L.df_estimate_workspace_bytes(self.estimator._engine(device), self.refiner._engine(device), B, H, W)
 
     def estimate(self, img, cloud, choose, obj, iteration, out=None):
@@ -212,7 +212,7 @@ class PoseEstimator:
             out = (torch.empty(B, 7, dtype=torch.float64, device=dev), torch.empty(B, 7, dtype=torch.float64, device=dev))
         pose_wo, pose = out
         L = _lib.lib()
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             hp, hr = self.estimator._engine(dev), self.refiner._engine(dev)
             need = L.df_estimate_workspace_bytes(hp, hr, B, H, W)
             if need == 0:

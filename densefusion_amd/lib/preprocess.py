@@ -74,7 +74,7 @@ def preprocess_objects(rgb, depth, label, objects, num_points, cam=YCB_CAM):
     cloud = torch.empty(B, num_points, 3, device=dev)
     choose = torch.empty(B, 1, num_points, dtype=torch.int64, device=dev)
     count = torch.empty(B, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         st = _lib.lib().df_preprocess_objects(rgb.data_ptr(), depth.data_ptr(), label.data_ptr(), F, IH, IW, d_desc.data_ptr(), B,
                                               H, W, num_points, cam["cx"], cam["cy"], cam["fx"], cam["fy"], cam["scale"], cam.get("cloud_div", 1.0),
                                               scratch.data_ptr(), img.data_ptr(), cloud.data_ptr(), choose.data_ptr(),

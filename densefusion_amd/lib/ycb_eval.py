@@ -31,7 +31,7 @@ def ycb_distances(rt_est, rt_gt, pts):
     B, M = pts.shape[0], pts.shape[1]
     add = torch.empty(B, dtype=torch.float64, device=pts.device)
     adi = torch.empty(B, dtype=torch.float64, device=pts.device)
-    with torch.cuda.device(pts.device):
+    with _lib.device_guard(pts.device):
         st = _lib.lib().df_ycb_distances(rt_est.data_ptr(), rt_gt.data_ptr(), pts.data_ptr(), B, M, add.data_ptr(),
                                          adi.data_ptr(), _lib.current_stream())
     _lib.check(st, "ycb_distances")

@@ -30,7 +30,7 @@ def conv2d_nhwc(x, w, bias=None, stride=1, pad=0, dil=1, act=0, res=None, prelu=
     d.OH, d.OW, d.Cout, d.out_ld, d.out_coff = OH, OW, Cout, out.shape[-1], out_coff
     d.res_ld, d.res_coff = (res.shape[-1] if res is not None else 0), 0
     d.KH, d.KW, d.stride, d.pad, d.dil, d.act = KH, KW, stride, pad, dil, act
-    with torch.cuda.device(x.device):
+    with _lib.device_guard(x.device):
         _lib.check(_lib.lib().df_conv2d_nhwc(ctypes.byref(d), _lib.current_stream()), "conv2d_nhwc")
     return out
 
@@ -69,7 +69,7 @@ class ConvNHWC(torch.autograd.Function):
         L = _lib.lib()
         d = _desc(x, w, None, stride, pad, dil)
         dx = dw = db = None
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 scratch = torch.empty_like(w)
@@ -99,7 +99,7 @@ def conv3x3_winograd_nhwc(x, w, bias=None, dil=1, act=0, res=None):
     d.res_ld, d.res_coff = (res.shape[-1] if res is not None else 0), 0
     d.KH, d.KW, d.stride, d.pad, d.dil, d.act = KH, KW, 1, dil, dil, act
     L = _lib.lib()
-    with torch.cuda.device(x.device):
+    with _lib.device_guard(x.device):
         need = L.df_conv3x3_winograd_scratch_bytes(ctypes.byref(d))
         if need == 0:
             _lib.check(-1, "conv3x3_winograd_scratch_bytes")

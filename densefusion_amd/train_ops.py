@@ -38,7 +38,7 @@ class ConvAct(torch.autograd.Function):
         L = _lib.lib()
         dy = dy.contiguous()
         dslope = None
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             if act:
                 g = torch.empty_like(dy)
                 if has_slope:
@@ -68,7 +68,7 @@ class MaxPool3s2(torch.autograd.Function):
         B, H, W, C = x.shape
         OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         y = torch.empty(B, OH, OW, C, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             _ck(_lib.lib().df_maxpool3s2_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, OH, OW, _st()), "maxpool3s2_fwd")
         ctx.save_for_backward(x)
         return y
@@ -79,7 +79,7 @@ class MaxPool3s2(torch.autograd.Function):
         B, H, W, C = x.shape
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             _ck(_lib.lib().df_maxpool3s2_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, H, W, C, dy.shape[1], dy.shape[2], _st()),
                 "maxpool3s2_bwd")
         return dx
@@ -91,7 +91,7 @@ class AdaptiveAvgPool(torch.autograd.Function):
         x = x.contiguous()
         B, H, W, C = x.shape
         y = torch.empty(B, s, s, C, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             _ck(_lib.lib().df_adaptive_avgpool(x.data_ptr(), y.data_ptr(), B, H, W, C, s, 0, _st()), "adaptive_avgpool")
         ctx.geom = (B, H, W, C, s)
         return y
@@ -101,7 +101,7 @@ class AdaptiveAvgPool(torch.autograd.Function):
         B, H, W, C, s = ctx.geom
         dy = dy.contiguous()
         dx = torch.empty(B, H, W, C, device=dy.device)
-        with torch.cuda.device(dy.device):
+        with _lib.device_guard(dy.device):
             _ck(_lib.lib().df_adaptive_avgpool(dy.data_ptr(), dx.data_ptr(), B, H, W, C, s, 1, _st()), "adaptive_avgpool_bwd")
         return dx, None
 
@@ -112,7 +112,7 @@ class Bilinear(torch.autograd.Function):
         x = x.contiguous()
         B, H, W, C = x.shape
         y = torch.empty(B, OH, OW, C, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             _ck(_lib.lib().df_bilinear(x.data_ptr(), y.data_ptr(), B, H, W, C, OH, OW, int(align), 0, _st()), "bilinear")
         ctx.geom = (B, H, W, C, OH, OW, int(align))
         return y
@@ -122,7 +122,7 @@ class Bilinear(torch.autograd.Function):
         B, H, W, C, OH, OW, align = ctx.geom
         dy = dy.contiguous()
         dx = torch.empty(B, H, W, C, device=dy.device)
-        with torch.cuda.device(dy.device):
+        with _lib.device_guard(dy.device):
             _ck(_lib.lib().df_bilinear(dy.data_ptr(), dx.data_ptr(), B, H, W, C, OH, OW, align, 1, _st()), "bilinear_bwd")
         return dx, None, None, None
 
@@ -132,7 +132,7 @@ class LogSoftmaxLast(torch.autograd.Function):
     def forward(ctx, x):
         x = x.contiguous()
         y = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             _ck(_lib.lib().df_logsoftmax(x.data_ptr(), None, y.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], 0, _st()), "logsoftmax")
         ctx.save_for_backward(y)
         return y
@@ -142,7 +142,7 @@ class LogSoftmaxLast(torch.autograd.Function):
         (y,) = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty_like(y)
-        with torch.cuda.device(y.device):
+        with _lib.device_guard(y.device):
             _ck(_lib.lib().df_logsoftmax(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel() // y.shape[-1], y.shape[-1], 1, _st()),
                 "logsoftmax_bwd")
         return dx
@@ -158,7 +158,7 @@ class Dropout2d(torch.autograd.Function):
         scale = torch.empty(B, C, device=x.device)
         y = torch.empty_like(x)
         L = _lib.lib()
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             _ck(L.df_dropout2d_mask(scale.data_ptr(), B * C, int(seed) & 0xFFFFFFFF, float(p), _st()), "dropout2d_mask")
             _ck(L.df_channel_scale(x.data_ptr(), scale.data_ptr(), y.data_ptr(), B, H * W, C, _st()), "channel_scale")
         ctx.save_for_backward(scale)
@@ -170,7 +170,7 @@ class Dropout2d(torch.autograd.Function):
         dy = dy.contiguous()
         B, H, W, C = dy.shape
         dx = torch.empty_like(dy)
-        with torch.cuda.device(dy.device):
+        with _lib.device_guard(dy.device):
             _ck(_lib.lib().df_channel_scale(dy.data_ptr(), scale.data_ptr(), dx.data_ptr(), B, H * W, C, _st()), "channel_scale")
         return dx, None, None
 
@@ -181,7 +181,7 @@ class GatherRows(torch.autograd.Function):
         x, idx = x.contiguous(), idx.contiguous()
         n, C = idx.numel(), x.shape[-1]
         y = torch.empty(n, C, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             _ck(_lib.lib().df_gather_rows(x.data_ptr(), idx.data_ptr(), y.data_ptr(), n, C, x.shape[0], 0, _st()), "gather_rows")
         ctx.save_for_backward(idx)
         ctx.rows = x.shape[0]
@@ -192,7 +192,7 @@ class GatherRows(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty(ctx.rows, dy.shape[-1], device=dy.device)
-        with torch.cuda.device(dy.device):
+        with _lib.device_guard(dy.device):
             _ck(_lib.lib().df_gather_rows(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), idx.numel(), dy.shape[-1], ctx.rows, 1, _st()),
                 "scatter_add_rows")
         return dx, None
@@ -204,7 +204,7 @@ class ColMean(torch.autograd.Function):
         x = x.contiguous()
         rows, C = x.shape
         y = torch.empty(C, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             _ck(_lib.lib().df_colmean(x.data_ptr(), y.data_ptr(), rows, C, 0, _st()), "colmean")
         ctx.geom = (rows, C)
         return y
@@ -214,7 +214,7 @@ class ColMean(torch.autograd.Function):
         rows, C = ctx.geom
         dy = dy.contiguous()
         dx = torch.empty(rows, C, device=dy.device)
-        with torch.cuda.device(dy.device):
+        with _lib.device_guard(dy.device):
             _ck(_lib.lib().df_colmean(dy.data_ptr(), dx.data_ptr(), rows, C, 1, _st()), "colmean_bwd")
         return dx
 
@@ -224,7 +224,7 @@ class Sigmoid(torch.autograd.Function):
     def forward(ctx, x):
         x = x.contiguous()
         y = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             _ck(_lib.lib().df_sigmoid(x.data_ptr(), None, y.data_ptr(), x.numel(), 0, _st()), "sigmoid")
         ctx.save_for_backward(y)
         return y
@@ -234,6 +234,6 @@ class Sigmoid(torch.autograd.Function):
         (y,) = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty_like(y)
-        with torch.cuda.device(y.device):
+        with _lib.device_guard(y.device):
             _ck(_lib.lib().df_sigmoid(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel(), 1, _st()), "sigmoid_bwd")
         return dx

@@ -58,7 +58,7 @@ class FlatAdam:
         f = self.flat
         if not f.data.is_cuda:
             raise RuntimeError("FlatAdam needs device tensors (no CPU path)")
-        with torch.cuda.device(f.data.device):
+        with _lib.device_guard(f.data.device):
             st = _lib.lib().df_adam_step(f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                          f.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.t, float(grad_scale),
                                          _lib.current_stream())
