@@ -516,7 +516,7 @@ static void posenet_points(Ctx &c, int B, int N, int Npad, const float *cloud, c
   // head layer 1: W[:, :384] . pointfeat + (W[:, 384:] . ap_x + b) -- the 1024 broadcast channels of the
   // 1408-wide input are identical for every point of an object, so they collapse into a per-object bias
   float *gbias = c.f((size_t)B * 1920);
-  c.conv(point_gemm(apx, 1024, 0, 1024, c.w("head1.wg"), c.w("head1.bias"), gbias, 1920, 0, 1920, B, ACT_NONE));   // one row per object
+  if (c.live()) launch_fc_rows(apx, 1024, 0, c.w("head1.wg"), c.w("head1.bias"), gbias, 1920, B, 1024, 1920, 1, 0, c.st);   // one row per object
   if (sel) {
     float *h1c = c.f((size_t)rows * 640), *h2c = c.f((size_t)rows * 256), *h3c = c.f((size_t)rows * 128), *conf = c.f((size_t)B * N);
     const float *w1 = c.w("head1.wpt"), *w2 = c.w("head2.w"), *b2 = c.w("head2.bias"), *w3 = c.w("head3.w"), *b3 = c.w("head3.bias");
@@ -618,12 +618,10 @@ static void refiner_iterate(Ctx &c, const RefinerBufs &r, int B, int N, int Npad
   p6.rows_per_group = Npad; p6.rows_valid = N; p6.colsum = r.partial;
   c.conv(p6);
   if (c.live()) launch_colsum_finish(r.partial, r.prow / B, r.apx, B, 1024, N, c.st);
-  // FC towers 1024 -> 512 -> 128 for r and t (lib/network.py:191-196): one row per object through the same MFMA kernel
-  c.conv(point_gemm(r.apx, 1024, 0, 1024, c.w("fc1.w"), c.w("fc1.bias"), r.f1, 1024, 0, 1024, B, ACT_RELU));
-  {
-    ConvParams p = point_gemm(r.f1, 1024, 0, 512, c.w("fc2.w"), c.w("fc2.bias"), r.f2, 256, 0, 128, B, ACT_RELU);
-    p.zcount = 2; p.z_in_coff = 512; p.z_wgt = 128 * 512; p.z_bias = 128; p.z_out_coff = 128;
-    c.conv(p);
+  // FC towers 1024 -> 512 -> 128 for r and t (lib/network.py:191-196): one row per object
+  if (c.live()) {
+    launch_fc_rows(r.apx, 1024, 0, c.w("fc1.w"), c.w("fc1.bias"), r.f1, 1024, B, 1024, 1024, 1, 1, c.st);
+    launch_fc_rows(r.f1, 1024, 512, c.w("fc2.w"), c.w("fc2.bias"), r.f2, 256, B, 512, 128, 2, 1, c.st);
   }
   if (c.live()) {
     launch_refiner_tail(r.f2, c.w("conv3_r.weight"), c.w("conv3_r.bias"), c.w("conv3_t.weight"), c.w("conv3_t.bias"), obj,

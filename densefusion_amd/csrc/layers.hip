@@ -393,6 +393,54 @@ __global__ __launch_bounds__(TPB) void colsum_finish_kernel(const float *__restr
   }
 }
 
+// y[r][g*nout + n] = act(w[g*nout + n] . x[r][g*x_gstride ...] + bias) for a handful of rows (one per object) against
+// wide weight matrices (the global-feature half of head layer 1, the refiner's FC towers): as a GEMM this is M <= 64,
+// i.e. a latency-bound chain of k-tiles on a few workgroups.  Here lane = row, a workgroup owns FC_COLS output columns
+// and its four waves each take a quarter of K: the weight rows are wave-uniform (scalar loads, every weight read once
+// per workgroup), the four partial sums meet in LDS and are added in a fixed order.
+constexpr int FC_COLS = 8;
+
+__global__ __launch_bounds__(256) void fc_rows_kernel(const float *__restrict__ x, int x_ld, int x_gstride, const float *__restrict__ w,
+                                                      const float *__restrict__ bias, float *__restrict__ y, int y_ld, int rows, int K,
+                                                      int nout, int groups, int relu) {
+  __shared__ float s_part[4][FC_COLS][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col0 = blockIdx.x * FC_COLS;                // FC_COLS | nout: a workgroup never straddles tower groups
+  const int g = col0 / nout;
+  const int kq = K >> 2, k0 = wave * kq;                 // this wave's quarter of K
+  for (int r0 = 0; r0 < rows; r0 += 64) {
+    const int r = r0 + lane;
+    const bool live = r < rows;
+    const float *xr = x + (size_t)(live ? r : r0) * x_ld + g * x_gstride + k0;
+    const float *wr = w + (size_t)col0 * K + k0;
+    float acc[FC_COLS];
+#pragma unroll
+    for (int c = 0; c < FC_COLS; ++c) acc[c] = 0.f;
+    for (int k = 0; k < kq; k += 4) {
+      const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + k);
+#pragma unroll
+      for (int c = 0; c < FC_COLS; ++c) {
+        const f32x4 wv = *reinterpret_cast<const f32x4 *>(wr + (size_t)c * K + k);      // wave-uniform address
+        acc[c] += (wv[0] * xv[0] + wv[1] * xv[1]) + (wv[2] * xv[2] + wv[3] * xv[3]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < FC_COLS; ++c) s_part[wave][c][lane] = acc[c];
+    __syncthreads();
+    // 256 threads finish 64 rows x FC_COLS columns: thread -> (column pair, row)
+    for (int e = threadIdx.x; e < FC_COLS * 64; e += 256) {
+      const int c = e >> 6, rr = e & 63;
+      if (r0 + rr < rows) {
+        float v = ((s_part[0][c][rr] + s_part[1][c][rr]) + (s_part[2][c][rr] + s_part[3][c][rr])) + (bias ? bias[col0 + c] : 0.f);
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[(size_t)(r0 + rr) * y_ld + col0 + c] = v;
+      }
+    }
+  }
+}
+
 // thread = (point, output j): j 0-3 quaternion, 4-6 translation, 7 confidence (sigmoid)
 __global__ __launch_bounds__(TPB) void head_final_kernel(const float *__restrict__ h3, const float *__restrict__ w_r,
                                                          const float *__restrict__ b_r, const float *__restrict__ w_t,
@@ -477,6 +525,12 @@ void launch_cloud_conv1(const float *cloud, const float *rt, const float *w, con
 void launch_colsum_finish(const float *partial, int rows_per_obj, float *mean, int B, int C, int N, hipStream_t st) {
   hipLaunchKernelGGL(colsum_finish_kernel, dim3(blocks_for((long)B * C)), dim3(TPB), 0, st, partial, rows_per_obj, mean,
                      B, C, N);
+}
+void launch_fc_rows(const float *x, int x_ld, int x_gstride, const float *w, const float *bias, float *y, int y_ld, int rows, int K,
+                    int nout, int groups, int relu, hipStream_t st) {
+  // K % 16 == 0 and nout % FC_COLS == 0 hold for every caller (K 512 / 1024, nout 128 .. 1920)
+  hipLaunchKernelGGL(fc_rows_kernel, dim3(nout * groups / FC_COLS), dim3(256), 0, st, x, x_ld, x_gstride, w, bias, y, y_ld, rows, K, nout,
+                     groups, relu);
 }
 void launch_head_final(const float *h3, const float *w_r, const float *b_r, const float *w_t, const float *b_t,
                        const float *w_c, const float *b_c, const int64_t *obj, int num_obj, float *out_r, float *out_t,

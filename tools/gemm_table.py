@@ -26,6 +26,14 @@ def main():
     for r in loss:
         print(f"{r[0]:>8} {r[1]:<44} {r[2]:8.1f} us {r[3]:6.1f} TF  excess {r[2] - r[2]*r[3]/125.0:7.1f} us")
     print(f"total excess {sum(r[2] - r[2]*r[3]/125.0 for r in rows)/1e3:.2f} ms of {tot/1e3:.2f} ms")
+    print("--- by shape class (N, K, kernel, z): launches, time, TFLOP/s, excess")
+    cls = {}
+    for r in rows:
+        key = " ".join(r[1].split()[1:])
+        c = cls.setdefault(key, [0, 0.0, 0.0])
+        c[0] += 1; c[1] += r[2]; c[2] += r[2] * r[3]
+    for key, c in sorted(cls.items(), key=lambda kv: -(kv[1][1] - kv[1][2] / 125.0))[:24]:
+        print(f"{key:<36} {c[0]:4d} {c[1]:9.1f} us {c[2]/c[1]:6.1f} TF  excess {c[1] - c[2]/125.0:8.1f} us")
 
 if __name__ == "__main__":
     main()
