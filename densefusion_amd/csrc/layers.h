@@ -39,7 +39,7 @@ void launch_cloud_conv1(const float *cloud, const float *rt, const float *w, con
 // mean over the points of each object from the GEMM's per-wave partial column sums
 void launch_colsum_finish(const float *partial, int rows_per_obj, float *mean, int B, int C, int N, hipStream_t st);
 // y[b][g*nout + n] = act(sum_k x[b][g*x_gstride + k] * W[g*nout + n][k] + bias[..]) for a handful of rows b (one per object);
-// needs K % 16 == 0, nout % 8 == 0
+// needs K % 128 == 0, nout % 8 == 0
 void launch_fc_rows(const float *x, int x_ld, int x_gstride, const float *w, const float *bias, float *y, int y_ld, int rows, int K,
                     int nout, int groups, int relu, hipStream_t st);
 // last head layer for the selected object only (lib/network.py:119-131): h3 [B][Npad][384] = r|t|c towers

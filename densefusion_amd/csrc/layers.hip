@@ -2,6 +2,7 @@
 // resampling, the gather + 1x1 + LogSoftmax tail, tiny per-point layers and row reductions.
 // All tensors fp32, channels-last; 16-byte vector accesses over the channel axis; 64-wide waves.
 #include "layers.h"
+#include <cstdlib>
 
 namespace df {
 namespace {
@@ -252,6 +253,66 @@ __global__ __launch_bounds__(TPB) void upconv_gather_kernel(const float *__restr
   }
 }
 
+// LDS-tiled form of the kernel above: a workgroup owns an 8 x 16 tile of output pixels and 16 output channels.  The
+// low-resolution rows / columns its 3x3 taps interpolate from (<= 7 x 11 pixels) are staged in LDS once, all nine tap
+// blocks of the 16 channels (<= 44 KB), so the 36 vector reads per output vector come from LDS and global traffic drops
+// from 36 to ~5.4 vector reads per output vector.  thread = (pixel of the tile, 4 channels).
+constexpr int UG_TY = 8, UG_TX = 16, UG_CC = 16, UG_RH = 7, UG_RW = 11;
+
+__global__ __launch_bounds__(512) void upconv_gather_tiled_kernel(const float *__restrict__ y, const float *__restrict__ bias,
+                                                                  const float *__restrict__ prelu, float *__restrict__ out, int B,
+                                                                  int h, int w, int Cout) {
+  __shared__ __attribute__((aligned(16))) float s_y[UG_RH * UG_RW * 9 * UG_CC];
+  const int OH = 2 * h, OW = 2 * w, ldy = 9 * Cout, chunks = Cout / UG_CC;
+  const float sh = OH > 1 ? (float)(h - 1) / (float)(OH - 1) : 0.f;
+  const float sw = OW > 1 ? (float)(w - 1) / (float)(OW - 1) : 0.f;
+  const int b = blockIdx.z / chunks, c0 = (blockIdx.z % chunks) * UG_CC;
+  const int Y0 = blockIdx.y * UG_TY, X0 = blockIdx.x * UG_TX;
+  // low-resolution window covering every tap of the tile
+  int r_lo, r_hi, c_lo, c_hi, dummy;
+  float fd0, fd1;
+  src_ac(max(Y0 - 1, 0), sh, h, r_lo, dummy, fd0, fd1);
+  src_ac(min(Y0 + UG_TY, OH - 1), sh, h, dummy, r_hi, fd0, fd1);
+  src_ac(max(X0 - 1, 0), sw, w, c_lo, dummy, fd0, fd1);
+  src_ac(min(X0 + UG_TX, OW - 1), sw, w, dummy, c_hi, fd0, fd1);
+  const int RH = r_hi - r_lo + 1, RW = c_hi - c_lo + 1;          // <= UG_RH, UG_RW
+  const int nvec = RH * RW * 9 * (UG_CC / 4);
+  for (int i = threadIdx.x; i < nvec; i += 512) {
+    const int c4 = i & 3;
+    int r = i >> 2;
+    const int tap = r % 9; r /= 9;
+    const int lx = r % RW, ly = r / RW;
+    reinterpret_cast<f32x4 *>(s_y)[i] =
+        *reinterpret_cast<const f32x4 *>(y + ((size_t)(b * h + r_lo + ly) * w + c_lo + lx) * ldy + tap * Cout + c0 + c4 * 4);
+  }
+  __syncthreads();
+  const int c4 = threadIdx.x & 3, pt = threadIdx.x >> 2;
+  const int py = Y0 + pt / UG_TX, px = X0 + pt % UG_TX;
+  if (py >= OH || px >= OW) return;
+  const Tap3 ty = taps_for(py, sh, h, OH), tx = taps_for(px, sw, w, OW);
+  const float slope = prelu[0];
+  f32x4 acc = *reinterpret_cast<const f32x4 *>(bias + c0 + c4 * 4);
+  const f32x4 *sv = reinterpret_cast<const f32x4 *>(s_y) + c4;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    if (!ty.ok[dy]) continue;
+    const int l0 = (ty.i0[dy] - r_lo) * RW, l1 = (ty.i1[dy] - r_lo) * RW;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      if (!tx.ok[dx]) continue;
+      const int tap = dy * 3 + dx, x0 = tx.i0[dx] - c_lo, x1 = tx.i1[dx] - c_lo;
+      const f32x4 v00 = sv[((l0 + x0) * 9 + tap) * 4], v01 = sv[((l0 + x1) * 9 + tap) * 4];
+      const f32x4 v10 = sv[((l1 + x0) * 9 + tap) * 4], v11 = sv[((l1 + x1) * 9 + tap) * 4];
+      const f32x4 v = lerp4(v00, v01, v10, v11, ty.w0[dy], ty.w1[dy], tx.w0[dx], tx.w1[dx]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = acc[e] > 0.f ? acc[e] : acc[e] * slope;
+  *reinterpret_cast<f32x4 *>(out + ((size_t)(b * OH + py) * OW + px) * Cout + c0 + c4 * 4) = acc;
+}
+
 // Tail of the colour branch, only at the N chosen pixels (lib/network.py:98-102).  Only those pixels of up_3's output
 // (lib/pspnet.py:75: bilinear x2, conv3x3 64->64, PReLU) are ever read, so the conv is evaluated there alone:
 // this kernel builds, per chosen pixel, the 3x3 patch of the UPSAMPLED input (each of the 9 taps bilinearly
@@ -396,44 +457,55 @@ __global__ __launch_bounds__(TPB) void colsum_finish_kernel(const float *__restr
 // y[r][g*nout + n] = act(w[g*nout + n] . x[r][g*x_gstride ...] + bias) for a handful of rows (one per object) against
 // wide weight matrices (the global-feature half of head layer 1, the refiner's FC towers): as a GEMM this is M <= 64,
 // i.e. a latency-bound chain of k-tiles on a few workgroups.  Here lane = row, a workgroup owns FC_COLS output columns
-// and its four waves each take a quarter of K: the weight rows are wave-uniform (scalar loads, every weight read once
-// per workgroup), the four partial sums meet in LDS and are added in a fixed order.
+// and its four waves each take a quarter of K: the weight block is staged in LDS once (coalesced; LDS broadcast reads in
+// the loop), the x vectors are fetched eight at a time per lane, the four partial sums meet in LDS and are added in a fixed
+// order.
 constexpr int FC_COLS = 8;
 
 __global__ __launch_bounds__(256) void fc_rows_kernel(const float *__restrict__ x, int x_ld, int x_gstride, const float *__restrict__ w,
                                                       const float *__restrict__ bias, float *__restrict__ y, int y_ld, int rows, int K,
                                                       int nout, int groups, int relu) {
-  __shared__ float s_part[4][FC_COLS][64];
+  extern __shared__ __attribute__((aligned(16))) float s_w[];      // [FC_COLS][K] weight block, then 4 x FC_COLS x 64 partial sums
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col0 = blockIdx.x * FC_COLS;                // FC_COLS | nout: a workgroup never straddles tower groups
   const int g = col0 / nout;
-  const int kq = K >> 2, k0 = wave * kq;                 // this wave's quarter of K
+  const int K4 = K >> 2, kq4 = K4 >> 2;                  // float4s per row, per wave quarter
+  float *s_part = s_w + FC_COLS * K;
+  // the workgroup's FC_COLS weight rows are contiguous in memory: one coalesced sweep into LDS
+  for (int i = threadIdx.x; i < FC_COLS * K4; i += 256)
+    reinterpret_cast<f32x4 *>(s_w)[i] = reinterpret_cast<const f32x4 *>(w + (size_t)col0 * K)[i];
   for (int r0 = 0; r0 < rows; r0 += 64) {
     const int r = r0 + lane;
     const bool live = r < rows;
-    const float *xr = x + (size_t)(live ? r : r0) * x_ld + g * x_gstride + k0;
-    const float *wr = w + (size_t)col0 * K + k0;
+    const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + (size_t)(live ? r : r0) * x_ld + g * x_gstride) + wave * kq4;
+    const f32x4 *wq = reinterpret_cast<const f32x4 *>(s_w) + wave * kq4;
     float acc[FC_COLS];
 #pragma unroll
     for (int c = 0; c < FC_COLS; ++c) acc[c] = 0.f;
-    for (int k = 0; k < kq; k += 4) {
-      const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + k);
+    __syncthreads();                                     // weight block staged / previous chunk's partials consumed
+    constexpr int PF = 8;                                // x vectors in flight per lane
+    for (int k = 0; k < kq4; k += PF) {
+      f32x4 xv[PF];
 #pragma unroll
-      for (int c = 0; c < FC_COLS; ++c) {
-        const f32x4 wv = *reinterpret_cast<const f32x4 *>(wr + (size_t)c * K + k);      // wave-uniform address
-        acc[c] += (wv[0] * xv[0] + wv[1] * xv[1]) + (wv[2] * xv[2] + wv[3] * xv[3]);
+      for (int u = 0; u < PF; ++u) xv[u] = xr[k + u];    // kq4 % PF == 0 (K % 128 == 0)
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+#pragma unroll
+        for (int c = 0; c < FC_COLS; ++c) {
+          const f32x4 wv = wq[c * K4 + k + u];           // same address in every lane: LDS broadcast
+          acc[c] += (wv[0] * xv[u][0] + wv[1] * xv[u][1]) + (wv[2] * xv[u][2] + wv[3] * xv[u][3]);
+        }
       }
     }
-    __syncthreads();
 #pragma unroll
-    for (int c = 0; c < FC_COLS; ++c) s_part[wave][c][lane] = acc[c];
+    for (int c = 0; c < FC_COLS; ++c) s_part[(wave * FC_COLS + c) * 64 + lane] = acc[c];
     __syncthreads();
-    // 256 threads finish 64 rows x FC_COLS columns: thread -> (column pair, row)
     for (int e = threadIdx.x; e < FC_COLS * 64; e += 256) {
       const int c = e >> 6, rr = e & 63;
       if (r0 + rr < rows) {
-        float v = ((s_part[0][c][rr] + s_part[1][c][rr]) + (s_part[2][c][rr] + s_part[3][c][rr])) + (bias ? bias[col0 + c] : 0.f);
+        float v = ((s_part[(0 * FC_COLS + c) * 64 + rr] + s_part[(1 * FC_COLS + c) * 64 + rr]) +
+                   (s_part[(2 * FC_COLS + c) * 64 + rr] + s_part[(3 * FC_COLS + c) * 64 + rr])) + (bias ? bias[col0 + c] : 0.f);
         if (relu) v = v > 0.f ? v : 0.f;
         y[(size_t)(r0 + rr) * y_ld + col0 + c] = v;
       }
@@ -508,6 +580,13 @@ void launch_final_logsoftmax(const float *z, const float *w, const float *bias, 
 }
 void launch_upconv_gather(const float *y, const float *bias, const float *prelu, float *out, int B, int h, int w, int Cout,
                           hipStream_t st) {
+  static const bool plain = getenv("DF_UPCONV_PLAIN") != nullptr;      // dev switch: the un-tiled kernel
+  const long gz = (long)B * (Cout / UG_CC);
+  if (!plain && Cout % UG_CC == 0 && gz <= 65535) {
+    dim3 grid((2 * w + UG_TX - 1) / UG_TX, (2 * h + UG_TY - 1) / UG_TY, (unsigned)gz);
+    hipLaunchKernelGGL(upconv_gather_tiled_kernel, grid, dim3(512), 0, st, y, bias, prelu, out, B, h, w, Cout);
+    return;
+  }
   hipLaunchKernelGGL(upconv_gather_kernel, dim3(blocks_for((long)B * 4 * h * w * (Cout / 4))), dim3(TPB), 0, st, y, bias, prelu,
                      out, B, h, w, Cout);
 }
@@ -528,8 +607,9 @@ void launch_colsum_finish(const float *partial, int rows_per_obj, float *mean, i
 }
 void launch_fc_rows(const float *x, int x_ld, int x_gstride, const float *w, const float *bias, float *y, int y_ld, int rows, int K,
                     int nout, int groups, int relu, hipStream_t st) {
-  // K % 16 == 0 and nout % FC_COLS == 0 hold for every caller (K 512 / 1024, nout 128 .. 1920)
-  hipLaunchKernelGGL(fc_rows_kernel, dim3(nout * groups / FC_COLS), dim3(256), 0, st, x, x_ld, x_gstride, w, bias, y, y_ld, rows, K, nout,
+  // K % 128 == 0 and nout % FC_COLS == 0 hold for every caller (K 512 / 1024, nout 128 .. 1920)
+  const size_t lds = ((size_t)FC_COLS * K + 4 * FC_COLS * 64) * sizeof(float);
+  hipLaunchKernelGGL(fc_rows_kernel, dim3(nout * groups / FC_COLS), dim3(256), lds, st, x, x_ld, x_gstride, w, bias, y, y_ld, rows, K, nout,
                      groups, relu);
 }
 void launch_head_final(const float *h3, const float *w_r, const float *b_r, const float *w_t, const float *b_t,

@@ -179,17 +179,33 @@ struct HeadSel {
   int *which;
 };
 
-template <int K4>     // dot of a K4*4-long row of `w` with the LDS vector `x`, lanes stride the float4s, wave-reduced
-__device__ __forceinline__ float wave_dot(const float *__restrict__ w, const float *x, int lane) {
-  float acc = 0.f;
+// NB outputs at once: dot products of NB consecutive K4*4-long rows of `w` (row stride K4*4) with the LDS vector `x`.
+// Lanes stride the float4s; all NB*ceil(K4/64) weight loads are issued before the first use, then the NB partial sums
+// are wave-reduced together (independent shuffle chains).
+template <int K4, int NB>
+__device__ __forceinline__ void wave_dots(const float *__restrict__ w, const float *x, int lane, float (&out)[NB]) {
+  constexpr int IT = (K4 + 63) / 64;
+  float4 wv[NB][IT];
 #pragma unroll
-  for (int k = lane; k < K4; k += 64) {
-    const float4 a = reinterpret_cast<const float4 *>(w)[k], v = reinterpret_cast<const float4 *>(x)[k];
-    acc += (a.x * v.x + a.y * v.y) + (a.z * v.z + a.w * v.w);
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int k = lane + 64 * i;
+      wv[n][i] = k < K4 ? reinterpret_cast<const float4 *>(w + (size_t)n * K4 * 4)[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+  for (int n = 0; n < NB; ++n) out[n] = 0.f;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int k = lane + 64 * i;
+    const float4 v = k < K4 ? reinterpret_cast<const float4 *>(x)[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) out[n] += (wv[n][i].x * v.x + wv[n][i].y * v.y) + (wv[n][i].z * v.z + wv[n][i].w * v.w);
   }
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-  return acc;
+  for (int d = 32; d >= 1; d >>= 1)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) out[n] += __shfl_xor(out[n], d);
 }
 
 // confidence of every point: thread = point, conv4_c row of the object + sigmoid -- the expression and summation order of
@@ -246,26 +262,37 @@ __global__ __launch_bounds__(256) void head_select_kernel(HeadSel a) {
   // 2. tower `tower` at the winning point
   for (int k = tid; k < 384; k += 256) s_x[k] = a.pf[row * 384 + k];
   __syncthreads();
-  for (int j = wave; j < 640; j += 4) {
-    const float v = wave_dot<96>(a.w1 + (size_t)(tower * 640 + j) * 384, s_x, lane) + a.gbias[(size_t)b * 1920 + tower * 640 + j];
-    if (lane == 0) s_h1[j] = fmaxf(v, 0.f);
+  constexpr int NB = 8;                      // outputs per wave step: 8 independent weight-row streams in flight
+  for (int j0 = wave * NB; j0 < 640; j0 += 4 * NB) {
+    float v[NB];
+    wave_dots<96, NB>(a.w1 + (size_t)(tower * 640 + j0) * 384, s_x, lane, v);
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+      if (lane == n) s_h1[j0 + n] = fmaxf(v[n] + a.gbias[(size_t)b * 1920 + tower * 640 + j0 + n], 0.f);
   }
   __syncthreads();
-  for (int j = wave; j < 256; j += 4) {
-    const float v = wave_dot<160>(a.w2 + ((size_t)tower * 256 + j) * 640, s_h1, lane) + a.b2[tower * 256 + j];
-    if (lane == 0) s_h2[j] = fmaxf(v, 0.f);
+  for (int j0 = wave * NB; j0 < 256; j0 += 4 * NB) {
+    float v[NB];
+    wave_dots<160, NB>(a.w2 + ((size_t)tower * 256 + j0) * 640, s_h1, lane, v);
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+      if (lane == n) s_h2[j0 + n] = fmaxf(v[n] + a.b2[tower * 256 + j0 + n], 0.f);
   }
   __syncthreads();
-  for (int j = wave; j < 128; j += 4) {
-    const float v = wave_dot<64>(a.w3 + ((size_t)tower * 128 + j) * 256, s_h2, lane) + a.b3[tower * 128 + j];
-    if (lane == 0) s_h3[j] = fmaxf(v, 0.f);
+  for (int j0 = wave * NB; j0 < 128; j0 += 4 * NB) {
+    float v[NB];
+    wave_dots<64, NB>(a.w3 + ((size_t)tower * 128 + j0) * 256, s_h2, lane, v);
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+      if (lane == n) s_h3[j0 + n] = fmaxf(v[n] + a.b3[tower * 128 + j0 + n], 0.f);
   }
   __syncthreads();
   const int nout = tower == 0 ? 4 : 3;
   if (wave < nout) {
     const float *w = tower == 0 ? a.w_r + (o * 4 + wave) * 128 : a.w_t + (o * 3 + wave) * 128;
-    const float v = wave_dot<32>(w, s_h3, lane) + (tower == 0 ? a.b_r[o * 4 + wave] : a.b_t[o * 3 + wave]);
-    if (lane == 0) s_y[wave] = v;
+    float v[1];
+    wave_dots<32, 1>(w, s_h3, lane, v);
+    if (lane == 0) s_y[wave] = v[0] + (tower == 0 ? a.b_r[o * 4 + wave] : a.b_t[o * 3 + wave]);
   }
   __syncthreads();
   if (tid != 0) return;
