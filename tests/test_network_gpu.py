@@ -226,3 +226,28 @@ def test_estimate_selects_the_same_pose_as_the_full_forward():
     t = cloud[ar, which] + out_t[ar, which]
     np.testing.assert_allclose(pose_wo[:, :4].cpu().numpy(), q.double().cpu().numpy(), rtol=0, atol=2e-5)
     np.testing.assert_allclose(pose_wo[:, 4:].cpu().numpy(), t.double().cpu().numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("H,W,B", [(480, 640, 1), (240, 320, 2), (160, 200, 2), (200, 240, 1)])
+def test_large_crops_vs_oracle(H, W, B):
+    """The largest crop the reference can produce (480x640, datasets/ycb/dataset.py:247-289) and the bench's large
+    buckets -- every Winograd-domain / direct choice of the trunk (dilation 1, 2, 4 on 20x25 ... 60x80 maps) and the
+    chosen-pixel up_3 path -- against the CPU oracle: raw network outputs and the refined pose."""
+    from densefusion_amd.lib.network import PoseEstimator
+    K, N = 21, 1000
+    est, ref = _nets(K, N, 29)
+    b = synth.make_batch(H * 7 + W, B, H, W, N, K)
+    T = lambda k: torch.from_numpy(b[k]).cuda()
+    _, pose = PoseEstimator(est, ref).estimate(T("img"), T("cloud"), T("choose"), T("obj"), 2)
+    r, t, c, emb = est(T("img"), T("cloud"), T("choose"), T("obj"))
+    sdp = dfnet._to_torch_sd(synth.make_state_dict(synth.posenet_spec(K), 29))
+    sdr = dfnet._to_torch_sd(synth.make_state_dict(synth.refiner_spec(K), 1029))
+    for i in range(B):
+        with torch.no_grad():
+            args = tuple(torch.from_numpy(b[k][i:i + 1]) for k in ("img", "cloud", "choose", "obj"))
+            o_r, o_t, o_c, o_e = dfnet.posenet_forward(sdp, *args)
+            cs = torch.sort(o_c.view(-1))[0]
+            _, opose = pose_math.estimate_pose(sdp, sdr, *args, 2)
+        _close(emb[i], o_e[0]); _close(r[i], o_r[0]); _close(t[i], o_t[0]); _close(c[i], o_c[0])
+        if float(cs[-1] - cs[-2]) > 1e-4:
+            assert _add(pose[i].cpu().numpy(), opose, b["model_points"][i]) < ADD_TOL
