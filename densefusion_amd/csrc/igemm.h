@@ -31,6 +31,7 @@ struct ConvParams {
   int rows_per_group = 0, rows_valid = 0, bias_group_ld = 0;
   // blockIdx.z "head" groups (the r/t/c towers): per-z element offsets
   int zcount = 1;
+  int ngroup = 0;   // column tiles per L2-resident weight group (0 = one group); set by launch_conv
   long z_in_coff = 0, z_wgt = 0, z_bias = 0, z_out_coff = 0;
 };
 

@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "igemm.h"
+#include <algorithm>
 
 namespace df {
 namespace {
@@ -247,7 +248,19 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
-  const int n_tile = wgid % tiles_n, m_tile = wgid / tiles_n;
+  // column-tile groups: when the weight operand is too big for an XCD's L2 (4 MB), the tiles are walked group by group
+  // (p.ngroup column tiles, all row blocks, next group ...) so that the group's weight slice stays L2-resident while the
+  // activation rows stream through once per group instead of every column tile missing on both operands
+  int n_tile, m_tile;
+  {
+    const int GN = p.ngroup > 0 && p.ngroup < tiles_n ? p.ngroup : tiles_n;
+    const int tiles_m = (int)(gridDim.x / tiles_n);
+    const int full = tiles_m * GN;
+    const int g = wgid / full, rem = wgid - g * full;
+    const int gw = min(GN, tiles_n - g * GN);
+    m_tile = rem / gw;
+    n_tile = g * GN + (rem - m_tile * gw);
+  }
   const int m0 = m_tile * BM, n0 = n_tile * BN;
   const int z = blockIdx.z;
   const int out_coff = p.out_coff + (int)(z * p.z_out_coff);
@@ -625,6 +638,13 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
   if (M * (long)p.out_ld >= (1L << 40) || (long)p.B * p.H * p.W >= (1L << 31))
     return set_error(DF_ERR_ARG, "conv: tensor too large for 32-bit pixel indexing");
   const TileCfg c = pick_cfg(p);
+  ConvParams pl = p;       // launch copy: + the column-tile group width
+  {
+    const size_t slice = (size_t)c.bn * p.KH * p.KW * p.Cin * sizeof(float);       // weights of one column tile
+    const long tn = (p.Cout + c.bn - 1) / c.bn;
+    static const long budget = getenv("DF_IGEMM_WGROUP_KB") ? atol(getenv("DF_IGEMM_WGROUP_KB")) * 1024L : 3L << 20;
+    if (budget > 0 && (size_t)tn * slice > (size_t)budget) pl.ngroup = (int)std::max<long>(1, budget / (long)slice);
+  }
   if (p.rows_per_group > 0 && (p.rows_per_group % c.bm))
     return set_error(DF_ERR_ARG, "conv: rows_per_group must be a multiple of %d", c.bm);
   const long tiles = ((M + c.bm - 1) / c.bm) * ((p.Cout + c.bn - 1) / c.bn);
@@ -653,11 +673,11 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
     }
     const bool bk32 = getenv("DF_IGEMM_BK64") == nullptr;      // dev switch: BK=64 measured slower on most 64x64 shapes
     if (c.bm == 128 && c.bn == 128)
-      hipLaunchKernelGGL((igemm_f32_v2_kernel<128, 128, 2, 2, 32>), grid, dim3(256), (size_t)2 * 256 * 36 * sizeof(float), st, p);
+      hipLaunchKernelGGL((igemm_f32_v2_kernel<128, 128, 2, 2, 32>), grid, dim3(256), (size_t)2 * 256 * 36 * sizeof(float), st, pl);
     else if (bk32)
-      hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2, 32>), grid, dim3(256), (size_t)2 * 128 * 36 * sizeof(float), st, p);
+      hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2, 32>), grid, dim3(256), (size_t)2 * 128 * 36 * sizeof(float), st, pl);
     else
-      hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2, 64>), grid, dim3(256), (size_t)2 * 128 * 68 * sizeof(float), st, p);
+      hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2, 64>), grid, dim3(256), (size_t)2 * 128 * 68 * sizeof(float), st, pl);
   } else if (c.bm == 128 && c.bn == 128) {
     hipLaunchKernelGGL((igemm_f32_kernel<128, 128, 2, 2>), grid, dim3(256), lds, st, p);
   } else {
