@@ -240,10 +240,38 @@ def cpu_baseline(buckets, gpu_poses, budget_s=14.0):
         if time.perf_counter() - t0 > budget_s or rnd >= 200:
             break
     dt = time.perf_counter() - t0
-    return ({"value": round(n / dt, 3), "unit": "poses/s", "cores": threads, "kind": "port",
+    extra = cpu_baseline_extras(threads)
+    return ({"value": round(n / dt, 3), "unit": "poses/s", "cores": threads, "kind": "port", **extra,
              "sample": f"{n} poses = {rnd} round(s) of one pose per crop size {CROPS}, K=21, N=1000, 2 refine iters, "
                        f"oracle/ (torch CPU fp32) in {dt:.1f} s"},
             {"max_add_m_vs_oracle": float(f"{worst_add:.3e}"), "objects_checked": checked, "tolerance_m": 1e-4})
+
+
+def cpu_baseline_extras(threads):
+    """SURVEY 8d's other two CPU figures, a few seconds each: BASELINE configs[0] (LineMOD, K=13, N=500, 80x80, PoseNet
+    forward only -- the reference's own CPU-runnable case) and the 1-NN at R=500, Q=500 000 (oracle/knn_ref.c, OpenMP)."""
+    from oracle import dfnet
+    from oracle.knn import knn_ref
+    sd = dfnet._to_torch_sd(synth.make_state_dict(synth.posenet_spec(13), WSEED + 7))
+    o = synth.make_object(99, 80, 80, 500, 13, cam=synth.LINEMOD_CAM)
+    args = tuple(torch.from_numpy(o[k])[None] if k in ("img", "cloud") else torch.from_numpy(o[k]) for k in ("img", "cloud", "choose", "obj"))
+    with torch.no_grad():
+        dfnet.posenet_forward(sd, *args)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 2.5:
+            dfnet.posenet_forward(sd, *args)
+            reps += 1
+        cfg1 = reps / (time.perf_counter() - t0)
+    rng = np.random.Generator(np.random.PCG64(5))
+    ref = rng.random((1, 3, 500), dtype=np.float32)
+    qry = rng.random((1, 3, 500000), dtype=np.float32)
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    knn_ref(ref, qry[:, :, :1000], 1)
+    t0 = time.perf_counter()
+    knn_ref(ref, qry, 1)
+    knn_ms = (time.perf_counter() - t0) * 1e3
+    return {"config1_linemod_posenet_forward_per_s": round(cfg1, 2), "knn_500x500k_ms": round(knn_ms, 1)}
 
 
 def main():
