@@ -379,13 +379,13 @@ def main():
                        "hipgraph": graph is not None, "bucket_streams": streams is not None, "sharding": f"objects round-robin over {world} rank(s), no data-path collective",
                        "reference_algorithm_gflop_per_step_per_gpu": round(gflop_step, 1),
                        "note": "reference_algorithm_* counts the FLOPs of the reference's own layer graph (SURVEY 8d); this build "
-                               "executes fewer (PSP fold, low-resolution up-convs, head fold), so that rate may exceed the fp32 peak"},
+                               "executes fewer (PSP fold, low-resolution up-convs, Winograd-domain trunk, chosen-pixel up_3, confidence-first heads: DESIGN.md 5), so that rate may exceed the fp32 peak"},
             "reference_algorithm_tflops_per_gpu": round(gflop_step * args.steps / dt / 1e3, 2),
         }
         ms, fl, by, n = profile_gemm(pe, buckets, min(args.steps, 5))
         traffic = measured_traffic()
         ach = fl / ms / 1e9 if ms > 0 else 0.0
-        out["roofline"] = {"kernel": "igemm_f32_kernel (implicit-GEMM conv / per-point GEMM, v_mfma_f32_32x32x2_f32)",
+        out["roofline"] = {"kernel": "igemm_f32_v2_kernel (implicit-GEMM conv / per-point / Winograd-domain GEMM, v_mfma_f32_32x32x2_f32; all launches of a step)",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
                            "algorithmic_mb_per_launch": round(by / max(n, 1) / 1e6, 2),
