@@ -131,13 +131,31 @@ __global__ __launch_bounds__(512) void psp_pool_kernel(const float *__restrict__
   for (int c0 = 0; c0 < C; c0 += 128 * 4) {
     const int c = c0 + tx * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (c < C)
-      for (int y = y0 + ty; y < y1; y += 4)
-        for (int x = x0; x < x1; ++x) {
-          const f32x4 v = *reinterpret_cast<const f32x4 *>(in + ((size_t)(b * H + y) * W + x) * in_ld + in_coff + c);
+    if (c < C) {
+      // the window's pixels, flattened; this thread takes every 4th one, four loads in flight (the 1x1 bin walks the
+      // whole map: without the unrolling its chain of dependent loads set the kernel's duration)
+      const int bw = x1 - x0, npx = (y1 - y0) * bw;
+      const float *base = in + (size_t)b * H * W * in_ld + in_coff + c;
+      f32x4 a4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      int p = ty;
+      for (; p + 12 < npx; p += 16) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        for (int u = 0; u < 4; ++u) {
+          const int q = p + 4 * u, yy = y0 + q / bw, xx = x0 + q % bw;
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(base + ((size_t)yy * W + xx) * in_ld);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a4[u][e] += v[e];
         }
+      }
+      for (; p < npx; p += 4) {
+        const int yy = y0 + p / bw, xx = x0 + p % bw;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(base + ((size_t)yy * W + xx) * in_ld);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a4[0][e] += v[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = (a4[0][e] + a4[1][e]) + (a4[2][e] + a4[3][e]);
+    }
     s_part[ty][tx] = acc;
     __syncthreads();
     if (ty == 0 && c < C) {
