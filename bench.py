@@ -141,7 +141,7 @@ def bench_latency(est, ref, device):
         with torch.cuda.stream(side):
             pe.estimate(d["img"], d["cloud"], d["choose"], d["obj"], iters, out=res)
         torch.cuda.current_stream().wait_stream(side)
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             pe.estimate(d["img"], d["cloud"], d["choose"], d["obj"], iters, out=res)
         for _ in range(5):
             g.replay()
@@ -332,7 +332,7 @@ def main():
                 run_step(pe, buckets, streams)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime
                 run_step(pe, buckets, streams)
         except Exception as e:                 # noqa: BLE001
             print(f"[bench] hipGraph capture failed ({e}); running eagerly", file=sys.stderr)
