@@ -321,9 +321,12 @@ __global__ __launch_bounds__(512) void upconv_gather_tiled_kernel(const float *_
       const int tap = dy * 3 + dx, x0 = tx.i0[dx] - c_lo, x1 = tx.i1[dx] - c_lo;
       const f32x4 v00 = sv[((l0 + x0) * 9 + tap) * 4], v01 = sv[((l0 + x1) * 9 + tap) * 4];
       const f32x4 v10 = sv[((l1 + x0) * 9 + tap) * 4], v11 = sv[((l1 + x1) * 9 + tap) * 4];
-      const f32x4 v = lerp4(v00, v01, v10, v11, ty.w0[dy], ty.w1[dy], tx.w0[dx], tx.w1[dx]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] += v[e];
+      // the four corner weights once per tap, then 4 fused multiply-adds per channel (packed pairs on gfx950)
+      const float w00 = ty.w0[dy] * tx.w0[dx], w01 = ty.w0[dy] * tx.w1[dx], w10 = ty.w1[dy] * tx.w0[dx], w11 = ty.w1[dy] * tx.w1[dx];
+      acc = __builtin_elementwise_fma(v00, f32x4{w00, w00, w00, w00}, acc);
+      acc = __builtin_elementwise_fma(v01, f32x4{w01, w01, w01, w01}, acc);
+      acc = __builtin_elementwise_fma(v10, f32x4{w10, w10, w10, w10}, acc);
+      acc = __builtin_elementwise_fma(v11, f32x4{w11, w11, w11, w11}, acc);
     }
   }
 #pragma unroll
