@@ -211,8 +211,9 @@ static int load_param(Net &n, const std::string &key, const float *src, int64_t 
       launch_wino_weight(dst, U, O, I, 0);
       hipDeviceSynchronize();
     }
-    if (e == hipSuccess && key.find(".up_") != std::string::npos && HW == 9) {
-      // PSPUpsample convs run as low-resolution 1x1 products per tap: keep a tap-major copy [9][O][I]
+    if (e == hipSuccess && (key.find(".up_1.") != std::string::npos || key.find(".up_2.") != std::string::npos) && HW == 9) {
+      // up_1 / up_2 run as low-resolution 1x1 products per tap: keep a tap-major copy [9][O][I] (up_3 runs as a plain
+      // [576]-deep GEMM on chosen-pixel patches and uses the packed layout as is)
       float *tm = dev_alloc(n, key + ".tm", (size_t)9 * O * I);
       if (!tm) return set_error(DF_ERR_LAUNCH, "load_param: hipMalloc failed");
       launch_tapmajor(dst, tm, O, I, 0);

@@ -8,15 +8,12 @@ namespace df {
 void launch_nchw3_to_nhwc4(const float *img, float *out, int B, int H, int W, hipStream_t st);
 // MaxPool2d(3, stride 2, pad 1) on NHWC (lib/extractors.py:84)
 void launch_maxpool3s2(const float *in, float *out, int B, int H, int W, int C, int OH, int OW, hipStream_t st);
-// nn.Upsample(scale_factor=2, bilinear, align_corners=True) on NHWC (lib/pspnet.py:31)
-void launch_upsample2x_ac(const float *in, float *out, int B, int H, int W, int C, hipStream_t st);
 // AdaptiveAvgPool2d(s) for s in {1,2,3,6} (lib/pspnet.py:15-17); in = NHWC rows of width in_ld at channel
 // offset in_coff; out = 4 stage blocks of B*36 rows each ([4][B*36][C]; stage s fills its first B*s*s rows)
 void launch_psp_pool(const float *in, int in_ld, int in_coff, float *out, int B, int H, int W, int C, hipStream_t st);
 // sum over the 4 stages of F.upsample(size=(H,W), bilinear, align_corners=False) (lib/pspnet.py:22) of the
 // stage maps z ([4][B*36][C], already multiplied by the folded stage x bottleneck weights) -> out [B][H][W][C]
 void launch_psp_prior_sum(const float *z, float *out, int B, int H, int W, int C, hipStream_t st);
-void launch_transpose2d(const float *in, float *out, int R, int C, hipStream_t st);
 // PSPUpsample (x2 bilinear align_corners=True -> conv3x3 pad 1 -> PReLU, lib/pspnet.py:27-37) from the nine
 // low-resolution 1x1 products y [B][h][w][9*Cout] (tap-major): out [B][2h][2w][Cout].  See layers.hip.
 void launch_upconv_gather(const float *y, const float *bias, const float *prelu, float *out, int B, int h, int w, int Cout,

@@ -82,30 +82,6 @@ __device__ inline f32x4 lerp4(const f32x4 &v00, const f32x4 &v01, const f32x4 &v
   return o;
 }
 
-__global__ __launch_bounds__(TPB) void upsample2x_ac_kernel(const float *__restrict__ in, float *__restrict__ out,
-                                                            int B, int H, int W, int C4) {
-  const int OH = 2 * H, OW = 2 * W;
-  const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
-  const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
-  const long total = (long)B * OH * OW * C4;
-  const f32x4 *src = reinterpret_cast<const f32x4 *>(in);
-  for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
-    const int c = (int)(i % C4);
-    long r = i / C4;
-    const int ox = (int)(r % OW); r /= OW;
-    const int oy = (int)(r % OH);
-    const int b = (int)(r / OH);
-    int y0, y1, x0, x1;
-    float wy0, wy1, wx0, wx1;
-    src_ac(oy, sh, H, y0, y1, wy0, wy1);
-    src_ac(ox, sw, W, x0, x1, wx0, wx1);
-    const long base = (long)b * H * W;
-    const f32x4 v00 = src[(base + (long)y0 * W + x0) * C4 + c], v01 = src[(base + (long)y0 * W + x1) * C4 + c];
-    const f32x4 v10 = src[(base + (long)y1 * W + x0) * C4 + c], v11 = src[(base + (long)y1 * W + x1) * C4 + c];
-    reinterpret_cast<f32x4 *>(out)[i] = lerp4(v00, v01, v10, v11, wy0, wy1, wx0, wx1);
-  }
-}
-
 __device__ inline void psp_bin(int bin, int &s, int &local) {
   if (bin < 1) { s = 1; local = bin; }
   else if (bin < 5) { s = 2; local = bin - 1; }
@@ -201,14 +177,6 @@ __global__ __launch_bounds__(TPB) void psp_prior_sum_kernel(const float *__restr
       for (int e = 0; e < 4; ++e) acc[e] += v[e];
     }
     reinterpret_cast<f32x4 *>(out)[idx] = acc;
-  }
-}
-
-__global__ __launch_bounds__(TPB) void transpose2d_kernel(const float *__restrict__ in, float *__restrict__ out, int R, int Cc) {
-  const long total = (long)R * Cc;
-  for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
-    const long r = i / Cc, c = i - r * Cc;
-    out[c * R + r] = in[i];
   }
 }
 
@@ -579,18 +547,11 @@ void launch_maxpool3s2(const float *in, float *out, int B, int H, int W, int C, 
   hipLaunchKernelGGL(maxpool3s2_kernel, dim3(blocks_for((long)B * OH * OW * (C / 4))), dim3(TPB), 0, st, in, out, B, H, W,
                      C / 4, OH, OW);
 }
-void launch_upsample2x_ac(const float *in, float *out, int B, int H, int W, int C, hipStream_t st) {
-  hipLaunchKernelGGL(upsample2x_ac_kernel, dim3(blocks_for((long)B * 4 * H * W * (C / 4))), dim3(TPB), 0, st, in, out, B,
-                     H, W, C / 4);
-}
 void launch_psp_pool(const float *in, int in_ld, int in_coff, float *out, int B, int H, int W, int C, hipStream_t st) {
   hipLaunchKernelGGL(psp_pool_kernel, dim3(50, B), dim3(512), 0, st, in, in_ld, in_coff, out, B, H, W, C);
 }
 void launch_psp_prior_sum(const float *z, float *out, int B, int H, int W, int C, hipStream_t st) {
   hipLaunchKernelGGL(psp_prior_sum_kernel, dim3(blocks_for((long)B * H * W * (C / 4))), dim3(TPB), 0, st, z, out, B, H, W, C);
-}
-void launch_transpose2d(const float *in, float *out, int R, int C, hipStream_t st) {
-  hipLaunchKernelGGL(transpose2d_kernel, dim3(blocks_for((long)R * C)), dim3(TPB), 0, st, in, out, R, C);
 }
 void launch_up3_patches(const float *x, const int64_t *choose, float *patch, int B, int h, int wd, int N, int Npad, hipStream_t st) {
   hipLaunchKernelGGL(up3_patch_kernel, dim3(blocks_for((long)B * Npad * 9 * 16)), dim3(TPB), 0, st, x, choose, patch, B, h, wd, N, Npad);

@@ -4,13 +4,9 @@
 
 namespace df {
 
-// per object: arg-max confidence, normalised quaternion + (point + offset) there -> state[B][7] (fp64),
-// optional copy pose_wo[B][7], the fp32 R|T record rt[B][12] for the first refine pass, optional which[B]
-void launch_pose_select(const float *out_r, const float *out_t, const float *out_c, const float *cloud, int B, int N,
-                        double *pose_wo, double *state, float *rt, int *which, hipStream_t st);
-
 // eval loop only: confidence (conv4_c + sigmoid on the confidence tower's features h3c [B*Npad][128]) -> arg-max point,
-// then the r / t towers (head layers 1..4) at that one point, then the same pose record as launch_pose_select
+// then the r / t towers (head layers 1..4) at that one point, then the pose record: state[B][7] (fp64 quaternion + translation),
+// optional copy pose_wo[B][7], the fp32 R|T record rt[B][12] for the first refine pass, optional which[B]
 void launch_head_select(const float *h3c, const float *w_c, const float *b_c, const float *pf, const float *gbias, const float *w1,
                         const float *w2, const float *b2, const float *w3, const float *b3, const float *w_r, const float *b_r,
                         const float *w_t, const float *b_t, const int64_t *obj, int num_obj, const float *cloud, int B, int N, int Npad,

@@ -64,51 +64,6 @@ __device__ void write_rt(const double M[9], const double t[3], float *rt) {
   for (int e = 0; e < 3; ++e) rt[9 + e] = (float)t[e];
 }
 
-// one workgroup per object: arg-max confidence (first maximum wins, like torch.max), normalised quat and
-// points+offset at that pixel (eval_ycb.py:193-203)
-__global__ __launch_bounds__(256) void pose_select_kernel(const float *__restrict__ out_r, const float *__restrict__ out_t,
-                                                          const float *__restrict__ out_c, const float *__restrict__ cloud,
-                                                          int N, double *__restrict__ pose_wo, double *__restrict__ state,
-                                                          float *__restrict__ rt, int *__restrict__ which) {
-  __shared__ float s_v[256];
-  __shared__ int s_i[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  float best = -__builtin_inff();
-  int bi = 0x7fffffff;
-  for (int n = tid; n < N; n += 256) {
-    const float c = out_c[(size_t)b * N + n];
-    if (c > best) { best = c; bi = n; }       // ascending n per thread: first maximum kept
-  }
-  s_v[tid] = best; s_i[tid] = bi;
-  __syncthreads();
-  for (int d = 128; d >= 1; d >>= 1) {
-    if (tid < d) {
-      const float ov = s_v[tid + d];
-      const int oi = s_i[tid + d];
-      if (ov > s_v[tid] || (ov == s_v[tid] && oi < s_i[tid])) { s_v[tid] = ov; s_i[tid] = oi; }
-    }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    int wm = s_i[0];
-    if (wm < 0 || wm >= N) wm = 0;             // all-NaN confidences
-    const float *q = out_r + ((size_t)b * N + wm) * 4;
-    const float nrm = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    double st[7];
-    for (int e = 0; e < 4; ++e) st[e] = (double)(q[e] / nrm);
-    for (int e = 0; e < 3; ++e)
-      st[4 + e] = (double)(cloud[((size_t)b * N + wm) * 3 + e] + out_t[((size_t)b * N + wm) * 3 + e]);
-    for (int e = 0; e < 7; ++e) {
-      state[b * 7 + e] = st[e];
-      if (pose_wo) pose_wo[b * 7 + e] = st[e];
-    }
-    double M[9];
-    quat_to_mat(st, M);
-    write_rt(M, st + 4, rt + b * 12);
-    if (which) which[b] = wm;
-  }
-}
-
 // one wave per object: last refiner layer for the selected object (lib/network.py:198-204), then
 // normalise, compose with the running pose and refresh R|T (eval_ycb.py:213-229)
 __global__ __launch_bounds__(64) void refiner_tail_kernel(const float *__restrict__ f2, const float *__restrict__ w_r,
@@ -296,7 +251,7 @@ __global__ __launch_bounds__(256) void head_select_kernel(HeadSel a) {
   }
   __syncthreads();
   if (tid != 0) return;
-  // 3. pose record (same arithmetic as pose_select_kernel)
+  // 3. pose record (eval_ycb.py:197-203): normalised quaternion, point + offset, and the fp32 R|T the refiner's cloud kernel reads
   if (tower == 0) {
     const float nrm = sqrtf(s_y[0] * s_y[0] + s_y[1] * s_y[1] + s_y[2] * s_y[2] + s_y[3] * s_y[3]);
     double q[4], M[9];
@@ -319,11 +274,6 @@ __global__ __launch_bounds__(256) void head_select_kernel(HeadSel a) {
 }
 
 }  // namespace
-
-void launch_pose_select(const float *out_r, const float *out_t, const float *out_c, const float *cloud, int B, int N,
-                        double *pose_wo, double *state, float *rt, int *which, hipStream_t st) {
-  hipLaunchKernelGGL(pose_select_kernel, dim3(B), dim3(256), 0, st, out_r, out_t, out_c, cloud, N, pose_wo, state, rt, which);
-}
 
 void launch_head_select(const float *h3c, const float *w_c, const float *b_c, const float *pf, const float *gbias, const float *w1,
                         const float *w2, const float *b2, const float *w3, const float *b3, const float *w_r, const float *b_r,
