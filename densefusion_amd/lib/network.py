@@ -120,11 +120,10 @@ class PoseNet(_EngineModule):
         (out_rx [B,N,4], out_tx [B,N,3], out_cx [B,N,1], emb [B,32,N])   (lib/network.py:95-132).
 
         In ``train()`` mode (or when gradients are required) the differentiable layer-by-layer path of
-        ``train_graph`` runs instead of the fused inference engine: bs = 1, Dropout2d active, autograd graph built."""
+        ``train_graph`` runs instead of the fused inference engine: Dropout2d active, autograd graph built (the reference
+        trains with bs = 1; B same-size objects per call are accepted and are equivalent to B calls)."""
         if self.training:
             from . import train_graph
-            if img.shape[0] != 1:
-                raise RuntimeError("PoseNet.forward in train() mode evaluates one object per call (bs = 1, like the reference)")
             return train_graph.posenet_forward(self, img.float(), x.float(), choose, obj, dropout=True)
         img, x = _dev_f32(img), _dev_f32(x)
         dev = img.device
@@ -158,11 +157,9 @@ class PoseRefineNet(_EngineModule):
 
     def forward(self, x, emb, obj):
         """x [B,N,3], emb [B,32,N], obj [B,1]|[B] -> (out_rx [B,4], out_tx [B,3])   (lib/network.py:187-206).
-        ``train()`` mode: differentiable path (``train_graph.refiner_forward``), bs = 1."""
+        ``train()`` mode: differentiable path (``train_graph.refiner_forward``)."""
         if self.training:
             from . import train_graph
-            if x.shape[0] != 1:
-                raise RuntimeError("PoseRefineNet.forward in train() mode evaluates one object per call (bs = 1)")
             return train_graph.refiner_forward(self, x.float(), emb.float(), obj)
         x, emb = _dev_f32(x), _dev_f32(emb)
         dev = x.device

@@ -89,50 +89,63 @@ def _pc(P, key, x, relu=True):
 _DROPOUT_CALLS = [0]
 
 
+def _object_means(x6, B, N):
+    """AvgPool1d(N) per object: x6 [B,N,1,C] -> [B,1,1,C]."""
+    C = x6.shape[-1]
+    return torch.stack([T.ColMean.apply(x6[b].reshape(N, C)) for b in range(B)]).reshape(B, 1, 1, C)
+
+
 def posenet_forward(net, img, x, choose, obj, dropout=True):
-    """Training-mode PoseNet.forward for ONE object (bs = 1, lib/network.py:95-132), differentiable."""
+    """Training-mode PoseNet.forward (lib/network.py:95-132), differentiable.  The reference runs one object per call
+    (bs = 1); B same-size objects may be passed together here -- every layer is per-sample, so the outputs and the
+    gradients are those of B separate calls."""
     P = dict(net.named_parameters())
     N = net.num_points
+    B, _, H, W = img.shape
     _DROPOUT_CALLS[0] += 1
-    feat = pspnet_forward(P, img, dropout, seed=int(torch.initial_seed() % 100003) * 7919 + _DROPOUT_CALLS[0])   # [1,H,W,32]
-    idx = choose.reshape(-1)
-    emb_pm = T.GatherRows.apply(feat.reshape(-1, 32), idx)               # [N,32]  (gather at the chosen pixels)
-    pts = x.reshape(1, N, 1, 3)
-    e = emb_pm.reshape(1, N, 1, 32)
+    feat = pspnet_forward(P, img, dropout, seed=int(torch.initial_seed() % 100003) * 7919 + _DROPOUT_CALLS[0])   # [B,H,W,32]
+    idx = (choose.reshape(B, N) + torch.arange(B, device=choose.device).reshape(B, 1) * (H * W)).reshape(-1)
+    emb_pm = T.GatherRows.apply(feat.reshape(-1, 32), idx)               # [B*N,32]  (gather at the chosen pixels)
+    pts = x.reshape(B, N, 1, 3)
+    e = emb_pm.reshape(B, N, 1, 32)
     x1, e1 = _pc(P, "feat.conv1", pts), _pc(P, "feat.e_conv1", e)
     x2, e2 = _pc(P, "feat.conv2", x1), _pc(P, "feat.e_conv2", e1)
     pf1, pf2 = torch.cat((x1, e1), 3), torch.cat((x2, e2), 3)
     x6 = _pc(P, "feat.conv6", _pc(P, "feat.conv5", pf2))
-    ap = T.ColMean.apply(x6.reshape(N, 1024)).reshape(1, 1, 1, 1024).expand(1, N, 1, 1024)    # AvgPool1d(N) + repeat
+    ap = _object_means(x6, B, N).expand(B, N, 1, 1024)                    # AvgPool1d(N) + repeat
     ap_x = torch.cat((pf1, pf2, ap), 3)                                  # 128 + 256 + 1024
     outs = {}
     for hname in "rtc":
         y = _pc(P, f"conv1_{hname}", ap_x)
         y = _pc(P, f"conv2_{hname}", y)
         y = _pc(P, f"conv3_{hname}", y)
-        outs[hname] = _pc(P, f"conv4_{hname}", y, relu=False).reshape(N, -1)
-    o = int(obj.reshape(-1)[0])
-    out_rx = outs["r"][:, o * 4:o * 4 + 4].reshape(1, N, 4)
-    out_tx = outs["t"][:, o * 3:o * 3 + 3].reshape(1, N, 3)
-    out_cx = T.Sigmoid.apply(outs["c"][:, o:o + 1].contiguous()).reshape(1, N, 1)
-    emb = emb_pm.t().reshape(1, 32, N)
+        outs[hname] = _pc(P, f"conv4_{hname}", y, relu=False).reshape(B, N, -1)
+    objs = [int(o) for o in obj.reshape(-1).tolist()]
+    out_rx = torch.stack([outs["r"][b, :, o * 4:o * 4 + 4] for b, o in enumerate(objs)])
+    out_tx = torch.stack([outs["t"][b, :, o * 3:o * 3 + 3] for b, o in enumerate(objs)])
+    conf = torch.stack([outs["c"][b, :, o:o + 1] for b, o in enumerate(objs)])
+    out_cx = T.Sigmoid.apply(conf.contiguous())
+    emb = emb_pm.reshape(B, N, 32).transpose(1, 2).contiguous()
     return out_rx, out_tx, out_cx, emb.detach()
 
 
 def refiner_forward(net, x, emb, obj):
-    """Training-mode PoseRefineNet.forward for ONE object (lib/network.py:187-206), differentiable."""
+    """Training-mode PoseRefineNet.forward (lib/network.py:187-206), differentiable; B objects per call allowed."""
     P = dict(net.named_parameters())
     N = net.num_points
-    pts = x.reshape(1, N, 1, 3)
-    e = emb.reshape(32, N).t().reshape(1, N, 1, 32)
+    B = x.shape[0]
+    pts = x.reshape(B, N, 1, 3)
+    e = emb.reshape(B, 32, N).transpose(1, 2).reshape(B, N, 1, 32)
     x1, e1 = _pc(P, "feat.conv1", pts), _pc(P, "feat.e_conv1", e)
     x2, e2 = _pc(P, "feat.conv2", x1), _pc(P, "feat.e_conv2", e1)
     pf3 = torch.cat((x1, e1, x2, e2), 3)
-    ap = T.ColMean.apply(_pc(P, "feat.conv6", _pc(P, "feat.conv5", pf3)).reshape(N, 1024)).reshape(1, 1, 1, 1024)
+    ap = _object_means(_pc(P, "feat.conv6", _pc(P, "feat.conv5", pf3)), B, N)
     outs = {}
     for hname in "rt":
         y = _pc(P, f"conv1_{hname}", ap)
         y = _pc(P, f"conv2_{hname}", y)
-        outs[hname] = _pc(P, f"conv3_{hname}", y, relu=False).reshape(-1)
-    o = int(obj.reshape(-1)[0])
-    return outs["r"][o * 4:o * 4 + 4].reshape(1, 4), outs["t"][o * 3:o * 3 + 3].reshape(1, 3)
+        outs[hname] = _pc(P, f"conv3_{hname}", y, relu=False).reshape(B, -1)
+    objs = [int(o) for o in obj.reshape(-1).tolist()]
+    out_rx = torch.stack([outs["r"][b, o * 4:o * 4 + 4] for b, o in enumerate(objs)])
+    out_tx = torch.stack([outs["t"][b, o * 3:o * 3 + 3] for b, o in enumerate(objs)])
+    return out_rx, out_tx

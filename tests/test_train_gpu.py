@@ -82,3 +82,77 @@ def test_refiner_training_step_gradients():
     dis.backward()
     for key, p in net.named_parameters():
         _close(p.grad, psd[key].grad, 2e-3, key)
+
+
+def test_batched_training_pass_equals_separate_passes():
+    """B same-size objects in one differentiable pass (forward + loss per object + one backward) give the outputs and
+    the accumulated parameter gradients of B separate bs = 1 passes (the reference's accumulation, tools/train.py:131-170)."""
+    from densefusion_amd.lib import train_graph
+    from densefusion_amd.lib.loss import Loss
+    from densefusion_amd.lib.loss_refiner import Loss_refine
+    from densefusion_amd.lib.network import PoseNet, PoseRefineNet
+    K, N, H, W, M, B = 3, 128, 40, 80, 60, 3
+    sd = synth.make_state_dict(synth.posenet_spec(K), 17)
+    objs = [synth.make_object(300 + i, H, W, N, K, num_points_mesh=M) for i in range(B)]
+    for i, o in enumerate(objs):
+        o["obj"][0] = i % K
+    crit = Loss(M, [1])
+    dev = torch.device("cuda:0")
+    T = lambda o, k: torch.from_numpy(o[k])[None].to(dev)
+
+    def grads(batched):
+        net = PoseNet(N, K)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net.to(dev).train()
+        outs = []
+        if batched:
+            img = torch.cat([T(o, "img") for o in objs]); x = torch.cat([T(o, "cloud") for o in objs])
+            ch = torch.cat([T(o, "choose") for o in objs]); ob = torch.cat([T(o, "obj") for o in objs])
+            r, t, c, emb = train_graph.posenet_forward(net, img, x, ch, ob, dropout=False)
+            total = 0
+            for b, o in enumerate(objs):
+                total = total + crit(r[b:b + 1], t[b:b + 1], c[b:b + 1], T(o, "target"), T(o, "model_points"), T(o, "obj"), T(o, "cloud"), 0.015, False)[0]
+            total.backward()
+            outs = [r, c, emb]
+        else:
+            rs, cs, es = [], [], []
+            for o in objs:
+                r, t, c, emb = train_graph.posenet_forward(net, T(o, "img"), T(o, "cloud"), T(o, "choose"), T(o, "obj"), dropout=False)
+                crit(r, t, c, T(o, "target"), T(o, "model_points"), T(o, "obj"), T(o, "cloud"), 0.015, False)[0].backward()
+                rs.append(r); cs.append(c); es.append(emb)
+            outs = [torch.cat(rs), torch.cat(cs), torch.cat(es)]
+        return outs, {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    (r1, c1, e1), g1 = grads(True)
+    (r2, c2, e2), g2 = grads(False)
+    _close(r1, r2.cpu(), 1e-5, "out_rx"); _close(c1, c2.cpu(), 1e-5, "out_cx"); _close(e1, e2.cpu(), 1e-5, "emb")
+    assert set(g1) == set(g2) and len(g1) >= 60
+    for k in g1:
+        _close(g1[k], g2[k].cpu(), 5e-4, k)
+
+    # refiner: same statement
+    sdr = synth.make_state_dict(synth.refiner_spec(K), 1017)
+    critr = Loss_refine(M, [1])
+
+    def rgrads(batched):
+        net = PoseRefineNet(N, K)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sdr.items()})
+        net.to(dev).train()
+        emb = e1.detach()
+        if batched:
+            x = torch.cat([T(o, "cloud") for o in objs]); ob = torch.cat([T(o, "obj") for o in objs])
+            pr, pt = net(x, emb, ob)
+            total = 0
+            for b, o in enumerate(objs):
+                total = total + critr(pr[b:b + 1], pt[b:b + 1], T(o, "target"), T(o, "model_points"), T(o, "obj"), T(o, "cloud"))[0]
+            total.backward()
+        else:
+            for b, o in enumerate(objs):
+                pr, pt = net(T(o, "cloud"), emb[b:b + 1], T(o, "obj"))
+                critr(pr, pt, T(o, "target"), T(o, "model_points"), T(o, "obj"), T(o, "cloud"))[0].backward()
+        return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    h1, h2 = rgrads(True), rgrads(False)
+    assert set(h1) == set(h2) and len(h1) >= 20
+    for k in h1:
+        _close(h1[k], h2[k].cpu(), 5e-4, k)

@@ -30,3 +30,19 @@ def test_train_entry_point_both_phases(tmp_path):
     name = os.path.basename(ckpts[-1])
     train.main(common + ["--nepoch", "3", "--refine_margin", "1e9", "--decay_margin", "-1", "--resume_posenet", name])
     assert glob.glob(str(tmp_path / "models" / "pose_refine_model_*.pth")), "no refiner checkpoint written"
+
+
+def test_train_entry_point_shared_passes(tmp_path):
+    """--frames_per_pass: same-size frames of an accumulation window share a pass; both phases still run and learn."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import train
+    common = ["--dataset", "synthetic", "--num_objects", "2", "--num_points", "64", "--synthetic_train_frames", "16",
+              "--synthetic_test_frames", "4", "--batch_size", "4", "--frames_per_pass", "4", "--lr", "0.0005",
+              "--outf", str(tmp_path / "models"), "--log_dir", str(tmp_path / "logs")]
+    train.SyntheticPoseDataset.CROPS = [(40, 40), (40, 80)]
+    first = train.main(common + ["--nepoch", "2", "--refine_margin", "-1", "--decay_margin", "-1"])
+    best = train.main(common + ["--nepoch", "5", "--refine_margin", "-1", "--decay_margin", "-1"])
+    assert best == best and best < first + 1e-6
+    ckpts = sorted(glob.glob(str(tmp_path / "models" / "pose_model_*.pth")))
+    train.main(common + ["--nepoch", "3", "--refine_margin", "1e9", "--decay_margin", "-1", "--resume_posenet", os.path.basename(ckpts[-1])])
+    assert glob.glob(str(tmp_path / "models" / "pose_refine_model_*.pth"))

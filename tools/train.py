@@ -3,8 +3,8 @@
 
 Phase A trains PoseNet with the confidence-weighted ADD(-S) loss until the test distance drops below
 ``--refine_margin``; phase B freezes it and trains PoseRefineNet for ``--iteration`` refinement steps per frame.
-One frame per forward/backward (bs = 1, like the reference), ``--batch_size`` frames accumulated per optimizer
-step, Adam, per-epoch test pass, ``*_current.pth`` every 1000 frames and best-model checkpoints with the
+One frame per forward/backward by default (bs = 1, like the reference; ``--frames_per_pass P`` lets up to P frames of
+equal crop size out of one accumulation window share a pass), ``--batch_size`` frames accumulated per optimizer step, Adam, per-epoch test pass, ``*_current.pth`` every 1000 frames and best-model checkpoints with the
 reference's file names, so its eval scripts and ours load them.
 
 Data-parallel over the GPUs of one node (one process per GPU, ``torch.distributed`` backend "nccl" = RCCL over
@@ -65,6 +65,9 @@ def build_parser():
     ap.add_argument("--dataset", type=str, default="synthetic", help="synthetic | ycb | linemod")
     ap.add_argument("--dataset_root", type=str, default="")
     ap.add_argument("--batch_size", type=int, default=8, help="frames accumulated per optimizer step and GPU")
+    ap.add_argument("--frames_per_pass", type=int, default=1,
+                    help="frames of equal crop size, out of one accumulation window, that share a forward/backward pass (1 = the "
+                         "reference's bs = 1 passes; the gradients of a window are the same either way)")
     ap.add_argument("--workers", type=int, default=4)
     ap.add_argument("--lr", type=float, default=0.0001)
     ap.add_argument("--lr_rate", type=float, default=0.3)
@@ -154,6 +157,36 @@ def main(argv=None):
         f = lambda t: t.to(dev)[None]                # add the bs = 1 axis the DataLoader of the reference adds
         return f(points), choose.to(dev).reshape(1, 1, -1), f(img), f(target), f(model_points), idx.to(dev).reshape(1, 1)
 
+    def run_pass(frames):
+        """Forward + loss + backward of `frames` (same crop size) in one pass; returns their distances."""
+        points, choose, img = (torch.cat([f[k] for f in frames]) for k in (0, 1, 2))
+        idx = torch.cat([f[5] for f in frames])
+        if opt.refine_start:
+            with torch.no_grad():
+                pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx)
+                new_points, new_target = [], []
+                for b, f in enumerate(frames):
+                    _, dis, npt, ntg = criterion(pred_r[b:b + 1], pred_t[b:b + 1], pred_c[b:b + 1], f[3], f[4], f[5], f[0], opt.w, True)
+                    new_points.append(npt); new_target.append(ntg)
+            last = [None] * len(frames)
+            for _ in range(opt.iteration):
+                pr, pt = refiner(torch.cat(new_points), emb, idx)
+                total = 0
+                for b, f in enumerate(frames):
+                    dis, new_points[b], new_target[b] = criterion_refine(pr[b:b + 1], pt[b:b + 1], new_target[b], f[4], f[5], new_points[b])
+                    total = total + dis
+                    last[b] = dis
+                total.backward()
+            return [float(d) for d in last]
+        pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx)
+        total, dists = 0, []
+        for b, f in enumerate(frames):
+            loss, dis, _, _ = criterion(pred_r[b:b + 1], pred_t[b:b + 1], pred_c[b:b + 1], f[3], f[4], f[5], f[0], opt.w, False)
+            total = total + loss
+            dists.append(dis)
+        total.backward()
+        return [float(d) for d in dists]
+
     best_test = np.inf
     st_time = time.time()
     frames_seen = 0
@@ -165,34 +198,34 @@ def main(argv=None):
         flat.zero_grad()
         train_count, train_dis_avg = 0, 0.0
         order = np.random.permutation(len(dataset))[rank::world]       # this rank's shard of the epoch
+        window = []
         for i in order:
             data = to_dev(dataset[int(i)])
             if data is None:
                 continue
-            points, choose, img, target, model_points, idx = data
-            if opt.refine_start:
-                with torch.no_grad():
-                    pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx)
-                    _, dis, new_points, new_target = criterion(pred_r, pred_t, pred_c, target, model_points, idx, points, opt.w, True)
-                for _ in range(opt.iteration):
-                    pred_r, pred_t = refiner(new_points, emb, idx)
-                    dis, new_points, new_target = criterion_refine(pred_r, pred_t, new_target, model_points, idx, new_points)
-                    dis.backward()
-            else:
-                pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx)
-                loss, dis, new_points, new_target = criterion(pred_r, pred_t, pred_c, target, model_points, idx, points, opt.w, False)
-                loss.backward()
-            train_dis_avg += float(dis)
-            train_count += 1
-            frames_seen += 1
-            if train_count % opt.batch_size == 0:
-                n = train_utils.allreduce_gradients(flat)             # the one collective of the training path
-                optimizer.step(grad_scale=1.0 / n)
-                flat.zero_grad()
-                log.info("Train time %s Epoch %d Batch %d Frame %d Avg_dis:%f", time.strftime("%Hh %Mm %Ss", time.gmtime(time.time() - st_time)),
-                         epoch, train_count // opt.batch_size, train_count, train_dis_avg / opt.batch_size)
-                train_dis_avg = 0.0
-            if train_count % 1000 == 0 and rank == 0:
+            window.append(data)
+            if len(window) < opt.batch_size:
+                continue
+            # one accumulation window = one optimizer step (tools/train.py:131-170); frames of equal crop size may share
+            # a pass (--frames_per_pass): the summed gradient of the window does not depend on how it is cut into passes
+            by_size = {}
+            for f in window:
+                by_size.setdefault(tuple(f[2].shape[-2:]), []).append(f)
+            for group in by_size.values():
+                for g0 in range(0, len(group), max(1, opt.frames_per_pass)):
+                    for d in run_pass(group[g0:g0 + max(1, opt.frames_per_pass)]):
+                        train_dis_avg += d
+            window = []
+            prev = train_count
+            train_count += opt.batch_size
+            frames_seen += opt.batch_size
+            n = train_utils.allreduce_gradients(flat)             # the one collective of the training path
+            optimizer.step(grad_scale=1.0 / n)
+            flat.zero_grad()
+            log.info("Train time %s Epoch %d Batch %d Frame %d Avg_dis:%f", time.strftime("%Hh %Mm %Ss", time.gmtime(time.time() - st_time)),
+                     epoch, train_count // opt.batch_size, train_count, train_dis_avg / opt.batch_size)
+            train_dis_avg = 0.0
+            if train_count // 1000 != prev // 1000 and rank == 0:
                 if opt.refine_start:
                     torch.save(refiner.state_dict(), "{0}/pose_refine_model_current.pth".format(opt.outf))
                 else:

@@ -1,5 +1,7 @@
 """Dev tool: training-step throughput (frames/s) on synthetic YCB-shaped frames (BASELINE configs[3] per GPU:
-K=21, N=1000, M=500, 8 frames accumulated per optimizer step, 5/21 objects symmetric)."""
+K=21, N=1000, M=500, 8 frames accumulated per optimizer step, 5/21 objects symmetric).
+usage: train_bench.py [frames_per_pass]   -- 1 (default) = the reference's bs = 1 passes; P > 1 = P same-size frames per
+differentiable pass (same gradients, larger GEMMs)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,28 +18,37 @@ def main():
     flat = train_utils.FlatParams(net); opt = train_utils.FlatAdam(flat, lr=1e-4)
     crit = Loss(M, [12, 15, 18, 19, 20])
     crops = [(80, 80), (120, 120), (120, 160), (160, 160), (160, 200), (200, 240), (240, 320)]
-    frames = []
-    for i in range(16):
-        H, W = crops[i % len(crops)]
-        o = synth.make_object(500 + i, H, W, N, K, M)
-        o["obj"][0] = [12, 3, 15, 7][i % 4]                 # half of the frames symmetric (KNN loss branch)
-        frames.append({k: torch.from_numpy(v).to(dev) for k, v in o.items()})
+    P = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    groups = []                                               # each group: P frames of one crop size
+    for gi in range(16 // P if P > 1 else 16):
+        H, W = crops[gi % len(crops)]
+        fr = []
+        for j in range(P):
+            o = synth.make_object(500 + gi * P + j, H, W, N, K, M)
+            o["obj"][0] = [12, 3, 15, 7][(gi + j) % 4]          # half of the frames symmetric (KNN loss branch)
+            fr.append({k: torch.from_numpy(v).to(dev) for k, v in o.items()})
+        groups.append(fr)
     def step(fr):
-        r, t, c, emb = net(fr["img"][None], fr["cloud"][None], fr["choose"], fr["obj"][None])
-        loss = crit(r, t, c, fr["target"][None], fr["model_points"][None], fr["obj"][None], fr["cloud"][None], 0.015, False)[0]
+        img = torch.stack([f["img"] for f in fr]); cloud = torch.stack([f["cloud"] for f in fr])
+        choose = torch.stack([f["choose"] for f in fr]); obj = torch.stack([f["obj"] for f in fr])
+        r, t, c, emb = net(img, cloud, choose, obj)
+        loss = 0
+        for b, f in enumerate(fr):
+            loss = loss + crit(r[b:b + 1], t[b:b + 1], c[b:b + 1], f["target"][None], f["model_points"][None], f["obj"][None], f["cloud"][None],
+                               0.015, False)[0]
         loss.backward()
         return loss
-    for fr in frames[:4]: step(fr)
+    for fr in groups[:2]: step(fr)
     opt.step(); flat.zero_grad(); torch.cuda.synchronize()
     t0 = time.perf_counter(); n = 0
     for rep in range(2):
-        for i, fr in enumerate(frames):
-            step(fr); n += 1
+        for fr in groups:
+            step(fr); n += len(fr)
             if n % acc == 0:
                 train_utils.allreduce_gradients(flat); opt.step(); flat.zero_grad()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"training: {n/dt:.1f} frames/s ({dt/n*1e3:.1f} ms per frame fwd+bwd, optimizer step every {acc} frames)")
+    print(f"training: {n/dt:.1f} frames/s ({dt/n*1e3:.1f} ms per frame fwd+bwd, {P} frame(s) per pass, optimizer step every {acc} frames)")
 
 if __name__ == "__main__":
     main()
