@@ -210,7 +210,7 @@ def host_threads():
     return max(1, min(n, int(os.environ.get("DF_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(buckets, gpu_poses, budget_s=14.0):
+def cpu_baseline(buckets, gpu_poses, budget_s=float(os.environ.get("DF_BENCH_CPU_BUDGET_S", "14"))):
     """The CPU oracle (port of the reference path) on this host: one pose per crop size per round."""
     from oracle import dfnet, pose_math
     threads = host_threads()
