@@ -22,4 +22,10 @@ def run(M, K, N, tile):
 
 for (M, K, N) in SHAPES:
     a = run(M, K, N, "a"); c = run(M, K, N, "c"); d = run(M, K, N, None)
-    print(f"M={M} K={K} N={N}: 128x128 {a[0]:7.1f} us {a[1]:6.1f} TF | 64x64 {c[0]:7.1f} us {c[1]:6.1f} TF | model {d[0]:7.1f} us")
+    extra = ""
+    if len(sys.argv) > 1:                                  # name of an env switch to flip for a third column
+        os.environ[sys.argv[1]] = "1"
+        e = run(M, K, N, None)
+        os.environ.pop(sys.argv[1])
+        extra = f" | {sys.argv[1]}=1 {e[0]:7.1f} us {e[1]:6.1f} TF"
+    print(f"M={M} K={K} N={N}: 128x128 {a[0]:7.1f} us {a[1]:6.1f} TF | 64x64 {c[0]:7.1f} us {c[1]:6.1f} TF | model {d[0]:7.1f} us {d[1]:6.1f} TF{extra}")
