@@ -121,3 +121,48 @@ def test_winograd_rejects_other_geometries():
     w5 = torch.randn(8, 5, 5, 8, device=dev)
     with pytest.raises(RuntimeError):
         ops.conv3x3_winograd_nhwc(x, w5)
+
+
+def test_random_geometries_direct_and_winograd():
+    """Seeded sweep over geometries the fixed lists do not hit: ragged M / Cout against both tile sizes, strides, dilations,
+    residual + bias + activations, weight operands large enough for the column-tile groups, and Winograd maps of arbitrary
+    (odd, tiny, non-square) size and dilation 1..4 -- each against an fp64 convolution."""
+    from densefusion_amd import ops
+    import random
+    rnd = random.Random(1234)
+    dev = torch.device("cuda:0")
+    cases = []
+    for _ in range(28):
+        k = rnd.choice([1, 1, 3, 3, 7])
+        cin = rnd.choice([4, 8, 16, 32, 64, 128, 256]) if k > 1 else 4 * rnd.randint(1, 96)
+        cout = 4 * rnd.randint(1, 80)
+        stride = rnd.choice([1, 1, 2]) if k > 1 else rnd.choice([1, 2])
+        dil = rnd.choice([1, 2, 4]) if k == 3 else 1
+        pad = dil * (k // 2) if rnd.random() < 0.8 else 0
+        cases.append((rnd.randint(1, 3), rnd.randint(1 + dil * (k - 1), 33), rnd.randint(1 + dil * (k - 1), 29), cin, cout, k, stride, pad, dil))
+    cases += [(1, 40, 25, 1024, 1536, 1, 1, 0, 1), (2, 9, 11, 512, 1028, 3, 1, 1, 1)]      # > 3 MB of weights: column-tile groups
+    for (B, H, W, Cin, Cout, k, s, p, d) in cases:
+        g = torch.Generator().manual_seed(B * 1000003 + H * 1009 + W * 13 + Cin + Cout + k)
+        x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+        w = (torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).to(dev)
+        b = torch.randn(Cout, generator=g).to(dev)
+        act = (B + H) % 3
+        slope = torch.tensor([0.25], device=dev) if act == 2 else None
+        want = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), b.double(), s, p, d).permute(0, 2, 3, 1)
+        res = torch.randn(*want.shape, generator=g).to(dev) if (H + W) % 2 else None
+        if res is not None:
+            want = want + res.double()
+        want = torch.relu(want) if act == 1 else (torch.where(want > 0, want, want * 0.25) if act == 2 else want)
+        got = ops.conv2d_nhwc(x, w, b, stride=s, pad=p, dil=d, act=act, res=res, prelu=slope)
+        err = float((got.double() - want).abs().max()) / max(float(want.abs().max()), 1e-9)
+        assert err < 2e-5, ((B, H, W, Cin, Cout, k, s, p, d), err)
+    for _ in range(16):
+        B, H, W, d = rnd.randint(1, 3), rnd.randint(1, 31), rnd.randint(1, 37), rnd.randint(1, 4)
+        Cin, Cout = 4 * rnd.randint(1, 40), 4 * rnd.randint(1, 40)
+        g = torch.Generator().manual_seed(H * 131 + W * 17 + d + Cin)
+        x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+        w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5).to(dev)
+        want = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), None, 1, d, d).permute(0, 2, 3, 1)
+        got = ops.conv3x3_winograd_nhwc(x, w, dil=d)
+        err = float((got.double() - want).abs().max()) / max(float(want.abs().max()), 1e-9)
+        assert err < 1e-5, ((B, H, W, Cin, Cout, d), err)

@@ -114,3 +114,21 @@ def test_nn_distance_mirror_matches_golden_and_bruteforce():
     assert np.array_equal(i2.cpu().numpy(), bi2.numpy())
     with pytest.raises(NotImplementedError):
         nn_distance(pc1.cuda(), pc2.cuda(), l1=True)
+
+
+def test_knn1_random_sizes_bit_exact(knn_cls):
+    """Seeded sweep over reference counts around the chunk size of the fused kernel (R % 8 tails, R < 8), query counts
+    around the workgroup sizes, clustered points with exact duplicates (ties) -- indices equal to the C restatement."""
+    rng = np.random.default_rng(77)
+    knn = knn_cls(1)
+    for _ in range(24):
+        B = int(rng.integers(1, 4))
+        R = int(rng.choice([1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 499, 500, 501, 1021, 2600]))
+        Q = int(rng.choice([1, 63, 64, 65, 255, 256, 257, 511, 513, 1023, 1025, 4097, 70001]))
+        ref = rng.standard_normal((B, 3, R)).astype(np.float32) * 0.1
+        qry = rng.standard_normal((B, 3, Q)).astype(np.float32) * 0.1
+        if R > 4:
+            ref[:, :, R // 2] = ref[:, :, 1]                      # duplicate reference: the lower index must win
+            qry[:, :, 0] = ref[:, :, 1]
+        got = knn(torch.from_numpy(ref), torch.from_numpy(qry)).cpu().numpy()
+        assert np.array_equal(got, knn_ref(ref, qry, 1)), (B, R, Q)
