@@ -47,13 +47,15 @@ class _EngineModule(nn.Module):
                 if not hasattr(mod, p):
                     mod.add_module(p, _Leaf())
                 mod = getattr(mod, p)
+            # fresh modules start like the reference's (torch defaults of nn.Conv*/nn.Linear: weight and bias ~
+            # U(-1/sqrt(fan_in), 1/sqrt(fan_in)); nn.PReLU 0.25) -- with un-normalised 0..255-scale inputs and no
+            # normalisation layers a hotter start (He-normal) overflows within a few optimizer steps
             if key.endswith(".conv.2.weight"):
-                t = torch.full(shape, 0.25)                      # nn.PReLU default
-            elif key.endswith(".bias"):
-                t = torch.zeros(shape)
+                t = torch.full(shape, 0.25)
             else:
-                fan_in = int(math.prod(shape[1:])) or 1
-                t = torch.randn(shape, generator=gen) * math.sqrt(2.0 / fan_in)
+                wshape = shape if not key.endswith(".bias") else dict(self._spec)[key[:-4] + "weight"]
+                bound = 1.0 / math.sqrt(int(math.prod(wshape[1:])) or 1)
+                t = (torch.rand(shape, generator=gen) * 2.0 - 1.0) * bound
             mod.register_parameter(parts[-1], nn.Parameter(t))
         self._handle = None
         self._handle_dev = None

@@ -123,9 +123,9 @@ def test_state_dict_contract_and_errors():
     assert [(k, tuple(v.shape)) for k, v in ref.state_dict().items()] == synth.refiner_spec(13)
     assert sum(p.numel() for p in est.parameters()) == 21440800
     est.cuda()
-    with pytest.raises(RuntimeError):                                       # train() mode is bs = 1 only, like the reference
-        est(torch.zeros(2, 3, 80, 80).cuda(), torch.zeros(2, 500, 3).cuda(), torch.zeros(2, 1, 500, dtype=torch.long).cuda(),
-            torch.zeros(2, 1, dtype=torch.long).cuda())
+    r2 = est(torch.zeros(2, 3, 80, 80).cuda(), torch.zeros(2, 500, 3).cuda(), torch.zeros(2, 1, 500, dtype=torch.long).cuda(),
+             torch.zeros(2, 1, dtype=torch.long).cuda())                    # train() mode: differentiable path, B objects per call
+    assert r2[0].shape == (2, 500, 4) and r2[0].grad_fn is not None and r2[3].shape == (2, 32, 500) and not r2[3].requires_grad
     est.eval()
     with pytest.raises(RuntimeError):                                       # CPU tensors are refused (no CPU path)
         est(torch.zeros(1, 3, 80, 80), torch.zeros(1, 500, 3), torch.zeros(1, 1, 500, dtype=torch.long), torch.zeros(1, 1, dtype=torch.long))

@@ -152,7 +152,7 @@ def main(argv=None):
 
     def to_dev(data):
         points, choose, img, target, model_points, idx = data
-        if points.dim() == 2:                       # the LineMOD loader's "lost detection" sentinel
+        if points.dim() == 1:                       # the LineMOD loader's "lost detection" sentinel: six LongTensor([0])
             return None
         f = lambda t: t.to(dev)[None]                # add the bs = 1 axis the DataLoader of the reference adds
         return f(points), choose.to(dev).reshape(1, 1, -1), f(img), f(target), f(model_points), idx.to(dev).reshape(1, 1)
@@ -177,7 +177,7 @@ def main(argv=None):
                     total = total + dis
                     last[b] = dis
                 total.backward()
-            return [float(d) for d in last]
+            return [float(d.detach()) for d in last]
         pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx)
         total, dists = 0, []
         for b, f in enumerate(frames):
@@ -185,7 +185,7 @@ def main(argv=None):
             total = total + loss
             dists.append(dis)
         total.backward()
-        return [float(d) for d in dists]
+        return [float(d.detach()) for d in dists]
 
     best_test = np.inf
     st_time = time.time()
