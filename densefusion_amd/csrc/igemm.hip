@@ -667,17 +667,12 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
     if (!attr2) {
       hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_f32_v2_kernel<128, 128, 2, 2, 32>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 36 * (int)sizeof(float));
-      hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_f32_v2_kernel<64, 64, 2, 2, 64>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 68 * (int)sizeof(float));
       attr2 = true;
     }
-    const bool bk32 = getenv("DF_IGEMM_BK64") == nullptr;      // dev switch: BK=64 measured slower on most 64x64 shapes
     if (c.bm == 128 && c.bn == 128)
       hipLaunchKernelGGL((igemm_f32_v2_kernel<128, 128, 2, 2, 32>), grid, dim3(256), (size_t)2 * 256 * 36 * sizeof(float), st, pl);
-    else if (bk32)
+    else      // (a BK = 64 form of the small tile was measured: 0.85-1.0x, dropped)
       hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2, 32>), grid, dim3(256), (size_t)2 * 128 * 36 * sizeof(float), st, pl);
-    else
-      hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2, 64>), grid, dim3(256), (size_t)2 * 128 * 68 * sizeof(float), st, pl);
   } else if (c.bm == 128 && c.bn == 128) {
     hipLaunchKernelGGL((igemm_f32_kernel<128, 128, 2, 2>), grid, dim3(256), lds, st, p);
   } else {

@@ -46,11 +46,11 @@ def main():
         variants = [("A", VA), ("B", VB)]
         for rnd in range(3):
             for name, env in variants:
-                for kk in ("DF_IGEMM_V1", "DF_IGEMM_BK64", "DF_IGEMM_TILE"):
+                for kk in ("DF_IGEMM_V1", "DF_IGEMM_TILE"):
                     os.environ.pop(kk, None)
                 os.environ.update(env)
                 res.setdefault(name, []).append(bench(x, w, pad, dil))
-        for kk in ("DF_IGEMM_V1", "DF_IGEMM_BK64", "DF_IGEMM_TILE"):
+        for kk in ("DF_IGEMM_V1", "DF_IGEMM_TILE"):
             os.environ.pop(kk, None)
         v1, v2 = min(res["A"]), min(res["B"])
         print(f"M={B*H*W:6d} N={Cout:4d} K={k*k*Cin:5d}: A {v1*1e3:7.1f} us {fl/v1/1e9:6.1f} TF | B {v2*1e3:7.1f} us {fl/v2/1e9:6.1f} TF | x{v1/v2:.3f}")
