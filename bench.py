@@ -280,6 +280,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--per-bucket", type=int, default=40, help="objects of each crop size per step and GPU")
+    ap.add_argument("--refine-iters", type=int, default=ITERS, help="refine iterations per pose (metric: 2; BASELINE configs[2] as written: 4)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-streams", action="store_true", help="run the crop-size buckets back to back on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -288,6 +289,7 @@ def main():
                                                       "the multi-rank path with several ranks on one GPU)")
     args = ap.parse_args()
 
+    globals()["ITERS"] = args.refine_iters
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
