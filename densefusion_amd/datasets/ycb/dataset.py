@@ -1,0 +1,116 @@
+"""``PoseDataset`` for YCB-Video -- host-side mirror of datasets/ycb/dataset.py:18-247 over the device-side input
+preparation, for frames that need no augmentation (``add_noise=False`` on real ``data/`` frames: the test list, or a
+real-only training list).
+
+Kept from the reference: constructor ``PoseDataset(mode, num_pt, add_noise, root, noise_trans, refine)``, the list /
+class files it reads (``dataset_config/{train,test}_data_list.txt``, ``classes.txt``, ``models/<class>/points.xyz``,
+``<frame>-{color,depth,label}.png``, ``<frame>-meta.mat``), the random choice of one object per frame with more than
+50 valid pixels (np.random.randint on numpy's global stream, :139-146), the label-extent box (``get_bbox`` :251-289), the
+two camera intrinsics by sequence number (:96-105) and ``factor_depth``, the model-point subset on Python's global
+``random`` stream (500 points, 2600 with ``refine``; :199-204), the 6-tuple, ``get_sym_list()`` / ``get_num_points_mesh()``.
+
+Different by design: mask, ``choose`` sampling, back-projection and the normalised crop run on the device
+(``df_preprocess_objects``; the pixel-subset rule of include/dfusion.h replaces np.random.shuffle) and the tensors stay
+there.  Refused loudly: ``add_noise=True`` and synthetic ``data_syn`` frames -- both need torchvision's ColorJitter, random
+occluders / backgrounds and pixel noise (:108-131,153-166), which is dataset augmentation outside this build.
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import scipy.io as scio
+import torch
+from PIL import Image
+
+from ...lib import preprocess as pp
+
+CAM_1 = dict(cx=312.9869, cy=241.3109, fx=1066.778, fy=1067.487)          # dataset.py:71-74
+CAM_2 = dict(cx=323.7872, cy=279.6921, fx=1077.836, fy=1078.189)          # :76-79, sequences >= 60
+IMG_H, IMG_W = 480, 640
+
+
+def get_bbox(label):
+    """Boolean mask of one object -> (rmin, rmax, cmin, cmax): its extents snapped to the border list, inside 480x640
+    (datasets/ycb/dataset.py:251-289)."""
+    rows, cols = np.flatnonzero(np.any(label, axis=1)), np.flatnonzero(np.any(label, axis=0))
+    rmin, rmax, cmin, cmax = int(rows[0]), int(rows[-1]) + 1, int(cols[0]), int(cols[-1]) + 1
+    r_b, c_b = pp._snap(rmax - rmin), pp._snap(cmax - cmin)
+    cr, cc = int((rmin + rmax) / 2), int((cmin + cmax) / 2)
+    rmin, rmax = cr - int(r_b / 2), cr + int(r_b / 2)
+    cmin, cmax = cc - int(c_b / 2), cc + int(c_b / 2)
+    if rmin < 0:
+        rmax, rmin = rmax - rmin, 0
+    if cmin < 0:
+        cmax, cmin = cmax - cmin, 0
+    if rmax > IMG_H:
+        rmin, rmax = rmin - (rmax - IMG_H), IMG_H
+    if cmax > IMG_W:
+        cmin, cmax = cmin - (cmax - IMG_W), IMG_W
+    return rmin, rmax, cmin, cmax
+
+
+class PoseDataset:
+    def __init__(self, mode, num_pt, add_noise, root, noise_trans, refine, dataset_config_dir="datasets/ycb/dataset_config",
+                 device="cuda", seed=0):
+        if add_noise:
+            raise NotImplementedError("PoseDataset(add_noise=True) needs torchvision's ColorJitter and the synthetic occluders; "
+                                      "not available in this build")
+        if mode not in ("train", "test"):
+            raise ValueError(f"mode must be train / test, got {mode!r}")
+        self.mode, self.num_pt, self.root, self.refine = mode, int(num_pt), root, refine
+        self.noise_trans = noise_trans
+        self.device, self.seed = torch.device(device), int(seed)
+        with open(f"{dataset_config_dir}/{mode}_data_list.txt") as f:
+            self.list = [ln.rstrip("\n") for ln in f if ln.strip()]
+        self.real = [n for n in self.list if n[:5] == "data/"]
+        self.syn = [n for n in self.list if n[:5] != "data/"]
+        self.length = len(self.list)
+        self.cld = {}
+        with open(f"{dataset_config_dir}/classes.txt") as f:
+            for class_id, name in enumerate((ln.strip() for ln in f if ln.strip()), start=1):
+                self.cld[class_id] = np.loadtxt(f"{root}/models/{name}/points.xyz", dtype=np.float64).reshape(-1, 3)
+        self.minimum_num_pt = 50
+        self.symmetry_obj_idx = [12, 15, 18, 19, 20]
+        self.num_pt_mesh_small, self.num_pt_mesh_large = 500, 2600
+
+    def __len__(self):
+        return self.length
+
+    def get_sym_list(self):
+        return self.symmetry_obj_idx
+
+    def get_num_points_mesh(self):
+        return self.num_pt_mesh_large if self.refine else self.num_pt_mesh_small
+
+    def __getitem__(self, index):
+        name = self.list[index]
+        if name[:8] == "data_syn":
+            raise NotImplementedError("synthetic frames (data_syn) need the reference's augmentation pipeline; not available in this build")
+        rgb = np.array(Image.open(f"{self.root}/{name}-color.png"))[:, :, :3].copy()
+        depth = np.array(Image.open(f"{self.root}/{name}-depth.png")).astype(np.uint16)
+        label = np.array(Image.open(f"{self.root}/{name}-label.png"))
+        meta = scio.loadmat(f"{self.root}/{name}-meta.mat")
+        cam = dict(CAM_2 if int(name[5:9]) >= 60 else CAM_1, scale=float(meta["factor_depth"][0][0]))
+        obj = meta["cls_indexes"].flatten().astype(np.int32)
+        while True:                                           # :139-146 (an object with enough valid pixels; numpy's global stream)
+            idx = np.random.randint(0, len(obj))
+            mask_label = label == obj[idx]
+            if np.count_nonzero(mask_label & (depth != 0)) > self.minimum_num_pt:
+                break
+        box = get_bbox(mask_label)
+        for _ in range(3):
+            random.uniform(-self.noise_trans, self.noise_trans)        # add_t is drawn even when unused (:171)
+        dev = self.device
+        img, cloud, choose, _count = pp.preprocess_objects(
+            torch.from_numpy(rgb[None]).to(dev), torch.from_numpy(depth[None].view(np.int16)).to(dev),
+            torch.from_numpy(label[None].astype(np.int32)).to(dev), [(0, int(obj[idx]), box, (self.seed * 1000003 + index) & 0xFFFFFFFF)],
+            self.num_pt, cam=cam)
+        pts = self.cld[int(obj[idx])]
+        keep_n = self.num_pt_mesh_large if self.refine else self.num_pt_mesh_small
+        drop = set(random.sample(range(len(pts)), len(pts) - keep_n))                 # :199-204 on Python's global stream
+        model_points = pts[[j for j in range(len(pts)) if j not in drop]]
+        pose = meta["poses"][:, :, idx]
+        target = np.dot(model_points, pose[:, 0:3].T) + pose[:, 3:4].flatten()[None]
+        return (cloud[0], choose[0], img[0], torch.from_numpy(target.astype(np.float32)).to(dev),
+                torch.from_numpy(model_points.astype(np.float32)).to(dev), torch.tensor([int(obj[idx]) - 1], dtype=torch.int64, device=dev))

@@ -43,3 +43,18 @@ def test_ply_reader_and_lists(tmp_path):
     D.PoseDataset.__init__(ds, "eval", 500, False, root, 0.0, True, device="cpu")
     assert len(ds) == 13 * 11 and ds.list_label[0].endswith("segnet_results/01_label/0000_label.png")
     assert ds._meta(2, 0)["obj_id"] == 2
+
+
+def test_ycb_dataset_get_bbox_matches_restatement():
+    from densefusion_amd.datasets.ycb import dataset as Y
+    from oracle import ycb_dataset_ref
+    rng = np.random.default_rng(4)
+    for _ in range(300):
+        m = np.zeros((480, 640), dtype=bool)
+        h, w = int(rng.integers(1, 480)), int(rng.integers(1, 640))
+        r0, c0 = int(rng.integers(0, 481 - h)), int(rng.integers(0, 641 - w))
+        m[r0:r0 + h, c0:c0 + w] = rng.random((h, w)) < 0.5
+        m[r0, c0] = m[r0 + h - 1, c0 + w - 1] = True
+        got = Y.get_bbox(m)
+        assert got == ycb_dataset_ref.get_bbox(m)
+        assert 0 <= got[0] < got[1] <= 480 and 0 <= got[2] < got[3] <= 640

@@ -1,0 +1,97 @@
+"""GPU: the YCB-Video ``PoseDataset`` mirror (real frames, no augmentation) on a fabricated dataset tree against the numpy
+restatement of datasets/ycb/dataset.py:90-217 (oracle/ycb_dataset_ref.py)."""
+import os
+import random
+
+import numpy as np
+import pytest
+import scipy.io as scio
+import torch
+from PIL import Image
+
+from densefusion_amd import synth
+from oracle import ycb_dataset_ref
+
+pytestmark = pytest.mark.gpu
+CLASSES = ["002_master_chef_can", "003_cracker_box", "004_sugar_box", "005_tomato_soup_can"]
+
+
+def make_tree(root, cfg, rng):
+    os.makedirs(cfg)
+    with open(f"{cfg}/classes.txt", "w") as f:
+        f.write("\n".join(CLASSES) + "\n")
+    for c in CLASSES:
+        os.makedirs(f"{root}/models/{c}")
+        np.savetxt(f"{root}/models/{c}/points.xyz", (rng.random((2700, 3)) - 0.5) * 0.2, fmt="%.6f")
+    names = []
+    for seq, frames in (("0001", 3), ("0060", 3)):
+        os.makedirs(f"{root}/data/{seq}")
+        for fr in range(frames):
+            name = f"data/{seq}/{fr + 1:06d}"
+            names.append(name)
+            rgb = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+            depth = rng.integers(4000, 15000, (480, 640)).astype(np.uint16)
+            depth[rng.random((480, 640)) < 0.08] = 0
+            label = np.zeros((480, 640), dtype=np.uint8)
+            present = [1, 3, 4] if fr % 2 == 0 else [2, 4]
+            for k, c in enumerate(present):
+                h, w = int(rng.integers(40, 200)), int(rng.integers(40, 260))
+                r0, c0 = int(rng.integers(0, 480 - h)), int(rng.integers(0, 640 - w))
+                label[r0:r0 + h, c0:c0 + w][rng.random((h, w)) < 0.7] = c
+            if fr == 1:
+                label[label == 4] = 0
+                label[5:9, 5:12] = 4                                  # object 4: 28 pixels only -> never selected (minimum 50)
+            poses = np.stack([np.concatenate([synth.quat_to_rot(synth.random_unit_quaternion(rng)), rng.normal(size=(3, 1)) * 0.2 + [[0], [0], [1.0]]], axis=1)
+                              for _ in present], axis=2)
+            Image.fromarray(rgb).save(f"{root}/{name}-color.png")
+            Image.fromarray(depth).save(f"{root}/{name}-depth.png")
+            Image.fromarray(label).save(f"{root}/{name}-label.png")
+            scio.savemat(f"{root}/{name}-meta.mat", {"cls_indexes": np.array(present, dtype=np.uint8)[:, None], "poses": poses,
+                                                     "factor_depth": np.array([[10000]], dtype=np.uint16)})
+    with open(f"{cfg}/test_data_list.txt", "w") as f:
+        f.write("\n".join(names) + "\n")
+    with open(f"{cfg}/train_data_list.txt", "w") as f:
+        f.write("\n".join(names[:2] + ["data_syn/000001"]) + "\n")
+    return names
+
+
+@pytest.mark.parametrize("refine", [False, True])
+def test_ycb_dataset_matches_restatement(tmp_path, refine):
+    from densefusion_amd.datasets.ycb.dataset import PoseDataset
+    rng = np.random.default_rng(3)
+    root, cfg = str(tmp_path / "YCB"), str(tmp_path / "cfg")
+    names = make_tree(root, cfg, rng)
+    N = 1000
+    ds = PoseDataset("test", N, False, root, 0.0, refine, dataset_config_dir=cfg, seed=5)
+    assert len(ds) == 6 and ds.get_sym_list() == [12, 15, 18, 19, 20] and ds.get_num_points_mesh() == (2600 if refine else 500)
+    for i, name in enumerate(names):
+        np.random.seed(100 + i); random.seed(200 + i)
+        got = ds[i]
+        np.random.seed(100 + i); random.seed(200 + i)
+        rgb = np.array(Image.open(f"{root}/{name}-color.png")); depth = np.array(Image.open(f"{root}/{name}-depth.png"))
+        label = np.array(Image.open(f"{root}/{name}-label.png")); meta = scio.loadmat(f"{root}/{name}-meta.mat")
+        obj = meta["cls_indexes"].flatten().astype(np.int32)
+        while True:                                           # the reference's selection loop (dataset.py:139-146)
+            idx = np.random.randint(0, len(obj))
+            if np.count_nonzero((label == obj[idx]) & (depth != 0)) > 50:
+                break
+        for _ in range(3):
+            random.uniform(0.0, 0.0)
+        cld = ds.cld[int(obj[idx])]
+        keep_n = 2600 if refine else 500
+        drop = set(random.sample(range(len(cld)), len(cld) - keep_n))
+        keep = [j for j in range(len(cld)) if j not in drop]
+        cloud, choose, img, target, model_points, box = ycb_dataset_ref.get_item(rgb, depth, label, meta, int(name[5:9]), idx, cld, keep, N,
+                                                                                  (5 * 1000003 + i) & 0xFFFFFFFF)
+        assert int(got[5][0]) == int(obj[idx]) - 1 and not (i == 1 and obj[idx] == 4)
+        assert tuple(got[2].shape[1:]) == (box[1] - box[0], box[3] - box[2])
+        assert torch.equal(got[1].cpu(), torch.from_numpy(choose))
+        assert torch.equal(got[0].cpu(), torch.from_numpy(cloud))
+        assert torch.equal(got[2].cpu(), torch.from_numpy(img))
+        np.testing.assert_array_equal(got[4].cpu().numpy(), model_points)
+        np.testing.assert_allclose(got[3].cpu().numpy(), target, rtol=0, atol=1e-7)
+    tr = PoseDataset("train", N, False, root, 0.0, refine, dataset_config_dir=cfg)
+    with pytest.raises(NotImplementedError):
+        tr[2]                                                 # data_syn frame
+    with pytest.raises(NotImplementedError):
+        PoseDataset("train", N, True, root, 0.03, refine, dataset_config_dir=cfg)
