@@ -52,7 +52,7 @@ def get_bbox(label):
 
 class PoseDataset:
     def __init__(self, mode, num_pt, add_noise, root, noise_trans, refine, dataset_config_dir="datasets/ycb/dataset_config",
-                 device="cuda", seed=0):
+                 device="cuda", seed=0, skip_synthetic=False):
         if add_noise:
             raise NotImplementedError("PoseDataset(add_noise=True) needs torchvision's ColorJitter and the synthetic occluders; "
                                       "not available in this build")
@@ -63,6 +63,8 @@ class PoseDataset:
         self.device, self.seed = torch.device(device), int(seed)
         with open(f"{dataset_config_dir}/{mode}_data_list.txt") as f:
             self.list = [ln.rstrip("\n") for ln in f if ln.strip()]
+        if skip_synthetic:                                    # real frames only (the synthetic ones need the augmentation pipeline)
+            self.list = [n for n in self.list if n[:5] == "data/"]
         self.real = [n for n in self.list if n[:5] == "data/"]
         self.syn = [n for n in self.list if n[:5] != "data/"]
         self.length = len(self.list)

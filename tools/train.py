@@ -13,8 +13,9 @@ xGMI): every rank trains on its own shard of the frame list, gradients live in O
 else is communicated.  Launch: ``python -m torch.distributed.run --nproc-per-node N tools/train.py ...``.
 
 ``--dataset synthetic`` trains on seeded synthetic frames (no dataset ships offline); ``ycb`` / ``linemod`` import
-``datasets.<name>.dataset.PoseDataset`` from the PYTHONPATH (the reference's loaders work unchanged: they return
-the 6-tuple cloud, choose, img, target, model_points, idx).
+``datasets.<name>.dataset.PoseDataset`` from the PYTHONPATH when it is there (the reference's loaders work unchanged: they
+return the 6-tuple cloud, choose, img, target, model_points, idx) and otherwise fall back to the built-in loaders
+(``densefusion_amd.datasets``), which prepare frames on the device but apply no augmentation.
 """
 from __future__ import annotations
 
@@ -97,15 +98,23 @@ def make_datasets(opt):
         tr = SyntheticPoseDataset("train", opt.num_points, opt.num_objects, opt.synthetic_train_frames)
         te = SyntheticPoseDataset("test", opt.num_points, opt.num_objects, opt.synthetic_test_frames)
         return tr, te
-    if opt.dataset == "ycb":
-        from datasets.ycb.dataset import PoseDataset
-        opt.num_objects, opt.num_points = 21, 1000
-    elif opt.dataset == "linemod":
-        from datasets.linemod.dataset import PoseDataset
-        opt.num_objects, opt.num_points = 13, 500
-    else:
+    if opt.dataset not in ("ycb", "linemod"):
         raise SystemExit("Unknown dataset")
-    return (PoseDataset("train", opt.num_points, True, opt.dataset_root, opt.noise_trans, opt.refine_start),
+    opt.num_objects, opt.num_points = (21, 1000) if opt.dataset == "ycb" else (13, 500)
+    try:        # the reference's loaders (with their augmentation: ColorJitter, occluders, noise) when they are on the PYTHONPATH
+        PoseDataset = __import__("datasets.%s.dataset" % opt.dataset, fromlist=["PoseDataset"]).PoseDataset
+        return (PoseDataset("train", opt.num_points, True, opt.dataset_root, opt.noise_trans, opt.refine_start),
+                PoseDataset("test", opt.num_points, False, opt.dataset_root, 0.0, opt.refine_start))
+    except ImportError:
+        logging.getLogger("train").warning("datasets.%s.dataset not importable: using the built-in loader WITHOUT augmentation "
+                                           "(no colour jitter / occluders / pose noise%s)", opt.dataset,
+                                           "; synthetic frames skipped" if opt.dataset == "ycb" else "")
+    if opt.dataset == "ycb":
+        from densefusion_amd.datasets.ycb.dataset import PoseDataset
+        return (PoseDataset("train", opt.num_points, False, opt.dataset_root, 0.0, opt.refine_start, skip_synthetic=True),
+                PoseDataset("test", opt.num_points, False, opt.dataset_root, 0.0, opt.refine_start))
+    from densefusion_amd.datasets.linemod.dataset import PoseDataset
+    return (PoseDataset("train", opt.num_points, False, opt.dataset_root, 0.0, opt.refine_start),
             PoseDataset("test", opt.num_points, False, opt.dataset_root, 0.0, opt.refine_start))
 
 
