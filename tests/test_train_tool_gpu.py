@@ -68,3 +68,20 @@ def test_train_entry_point_shared_passes(tmp_path, monkeypatch, caplog):
     assert 1e-4 < untrained < 10 and best == best and 1e-4 < best < 0.9 * untrained
     ckpts = sorted(glob.glob(str(tmp_path / "models" / "pose_model_*.pth")))
     _phase_b(train, common, os.path.basename(ckpts[-1]), caplog)
+
+
+def test_train_on_fabricated_linemod_tree_with_builtin_loader(tmp_path, caplog):
+    """--dataset linemod without the reference's loader on the PYTHONPATH: the built-in loader (device-side preparation, no
+    augmentation) feeds the trainer; one epoch over a fabricated tree runs and reports a finite test distance."""
+    import logging
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import train
+    from test_linemod_dataset_gpu import make_tree
+    tree = make_tree(str(tmp_path / "lm"), frames_per_obj=10)          # 'test' keeps line 10 of every list: 13 test frames
+    with caplog.at_level(logging.INFO, logger="train"):
+        best = train.main(["--dataset", "linemod", "--dataset_root", tree, "--nepoch", "2", "--batch_size", "8", "--frames_per_pass", "4",
+                           "--refine_margin", "-1", "--decay_margin", "-1", "--outf", str(tmp_path / "models"), "--log_dir", str(tmp_path / "logs")])
+    lines = [r.getMessage() for r in caplog.records]
+    assert any("built-in loader" in ln for ln in lines)
+    assert sum(ln.startswith("Train time") for ln in lines) >= 10 and 1e-4 < best < 10
+    assert glob.glob(str(tmp_path / "models" / "pose_model_1_*.pth"))
