@@ -48,6 +48,8 @@ SIGNATURES = {
     "df_ycb_distances": (_i, [_vp] * 3 + [_i, _i, _vp, _vp, _vp]),
     "df_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "df_maxpool3s2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "df_maxpool2x2_idx": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "df_maxunpool2x2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "df_maxpool3s2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "df_adaptive_avgpool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "df_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

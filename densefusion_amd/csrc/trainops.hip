@@ -316,6 +316,65 @@ extern "C" int df_sigmoid(const float *a, const float *y, float *out, int64_t n,
   return check_launch("sigmoid");
 }
 
+namespace {
+// MaxPool2d(2, stride 2, return_indices) / MaxUnpool2d(2, stride 2) of the SegNet encoder / decoder
+// (vanilla_segmentation/segnet.py:78-116), channels-last.  The "index" is the position 0..3 inside the 2x2 window (row-major),
+// first maximum wins (strict '>' scan, NaN taken like ATen's `val > max || isnan(val)`); one byte per element.
+__global__ __launch_bounds__(TB) void maxpool2x2_idx_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned char *__restrict__ idx,
+                                                            int B, int H, int W, int C) {
+  const int OH = H / 2, OW = W / 2;
+  const long total = (long)B * OH * OW * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH);
+    const int b = (int)(r / OH);
+    const float *p = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+    float best = p[0];
+    int bi = 0;
+    const float v1 = p[C], v2 = p[(size_t)W * C], v3 = p[(size_t)W * C + C];
+    if (v1 > best || v1 != v1) { best = v1; bi = 1; }
+    if (v2 > best || v2 != v2) { best = v2; bi = 2; }
+    if (v3 > best || v3 != v3) { best = v3; bi = 3; }
+    y[i] = best;
+    idx[i] = (unsigned char)bi;
+  }
+}
+
+__global__ __launch_bounds__(TB) void maxunpool2x2_kernel(const float *__restrict__ x, const unsigned char *__restrict__ idx,
+                                                          float *__restrict__ y, int B, int H, int W, int C) {   // H, W: pooled size
+  const long total = (long)B * H * W * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int ox = (int)(r % W); r /= W;
+    const int oy = (int)(r % H);
+    const int b = (int)(r / H);
+    const float v = x[i];
+    const int k = idx[i];
+    float *q = y + (((size_t)b * 2 * H + 2 * oy) * (2 * W) + 2 * ox) * C + c;
+    q[0] = k == 0 ? v : 0.f;
+    q[C] = k == 1 ? v : 0.f;
+    q[(size_t)2 * W * C] = k == 2 ? v : 0.f;
+    q[(size_t)2 * W * C + C] = k == 3 ? v : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int df_maxpool2x2_idx(const float *x, float *y, unsigned char *idx, int B, int H, int W, int C, df_stream_t stream) {
+  NN(x); NN(y); NN(idx);
+  if (B <= 0 || H < 2 || W < 2 || C <= 0 || (H & 1) || (W & 1)) return set_error(DF_ERR_ARG, "maxpool2x2_idx: need even H, W >= 2");
+  hipLaunchKernelGGL(maxpool2x2_idx_kernel, dim3(nblk((long)B * (H / 2) * (W / 2) * C)), dim3(TB), 0, ST, x, y, idx, B, H, W, C);
+  return check_launch("maxpool2x2_idx");
+}
+extern "C" int df_maxunpool2x2(const float *x, const unsigned char *idx, float *y, int B, int H, int W, int C, df_stream_t stream) {
+  NN(x); NN(y); NN(idx);
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return set_error(DF_ERR_ARG, "maxunpool2x2: bad sizes");
+  hipLaunchKernelGGL(maxunpool2x2_kernel, dim3(nblk((long)B * H * W * C)), dim3(TB), 0, ST, x, idx, y, B, H, W, C);
+  return check_launch("maxunpool2x2");
+}
+
 #include "layers.h"
 extern "C" int df_maxpool3s2_fwd(const float *x, float *y, int B, int H, int W, int C, int OH, int OW, df_stream_t stream) {
   NN(x); NN(y);

@@ -195,3 +195,40 @@ def make_batch(seed: int, B: int, H: int, W: int, num_points: int, num_obj: int,
     objs = [make_object(seed * 1000 + i, H, W, num_points, num_obj, num_points_mesh, cam)
             for i in range(B)]
     return {k: np.stack([o[k] for o in objs]) for k in objs[0]}
+
+
+# ---- SegNet (vanilla_segmentation/segnet.py): state-dict layout and seeded synthetic weights -------------------------
+_SEG_LAYERS = [("11", 3, 64), ("12", 64, 64), ("21", 64, 128), ("22", 128, 128), ("31", 128, 256), ("32", 256, 256), ("33", 256, 256),
+               ("41", 256, 512), ("42", 512, 512), ("43", 512, 512), ("51", 512, 512), ("52", 512, 512), ("53", 512, 512),
+               ("53d", 512, 512), ("52d", 512, 512), ("51d", 512, 512), ("43d", 512, 512), ("42d", 512, 512), ("41d", 512, 256),
+               ("33d", 256, 256), ("32d", 256, 256), ("31d", 256, 128), ("22d", 128, 128), ("21d", 128, 64), ("12d", 64, 64), ("11d", 64, None)]
+
+
+def segnet_spec(label_nbr=22, input_nbr=3):
+    """(key, shape) in the reference's state_dict order (conv then its bn, constructor order of segnet.py:12-70)."""
+    spec = []
+    for name, cin, cout in _SEG_LAYERS:
+        cin = input_nbr if name == "11" else cin
+        cout = label_nbr if cout is None else cout
+        spec += [(f"conv{name}.weight", (cout, cin, 3, 3)), (f"conv{name}.bias", (cout,))]
+        if name != "11d":
+            spec += [(f"bn{name}.weight", (cout,)), (f"bn{name}.bias", (cout,)), (f"bn{name}.running_mean", (cout,)),
+                     (f"bn{name}.running_var", (cout,)), (f"bn{name}.num_batches_tracked", ())]
+    return spec
+
+
+def make_segnet_state_dict(seed, label_nbr=22):
+    """Seeded synthetic SegNet weights: He-normal convs, BatchNorm scale / variance around 1, small shifts / means."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = {}
+    for key, shape in segnet_spec(label_nbr):
+        if key.endswith("num_batches_tracked"):
+            sd[key] = np.array(100, dtype=np.int64)
+        elif key.startswith("conv") and key.endswith("weight"):
+            fan_in = shape[1] * 9
+            sd[key] = (rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+        elif key.endswith("running_var") or (key.startswith("bn") and key.endswith("weight")):
+            sd[key] = rng.uniform(0.6, 1.4, shape).astype(np.float32)
+        else:
+            sd[key] = rng.uniform(-0.1, 0.1, shape).astype(np.float32)
+    return sd

@@ -141,6 +141,11 @@ int df_ycb_distances(const double *rt_est, const double *rt_gt, const double *pt
 int df_act_bwd(const float *dy, const float *y, float *dx, int64_t n, int act /*1 ReLU, 2 PReLU*/, const float *slope,
                float *dslope /* PReLU: += */, df_stream_t stream);
 int df_maxpool3s2_fwd(const float *x, float *y, int B, int H, int W, int C, int OH, int OW, df_stream_t stream);
+/* MaxPool2d(2, 2, return_indices) / MaxUnpool2d(2, 2) of the SegNet encoder / decoder (vanilla_segmentation/segnet.py:78-116),
+ * channels-last [B][H][W][C]; idx holds the winner's position 0..3 inside its 2x2 window (first maximum wins); unpool takes
+ * the POOLED size H x W and writes [B][2H][2W][C]. */
+int df_maxpool2x2_idx(const float *x, float *y, unsigned char *idx, int B, int H, int W, int C, df_stream_t stream);
+int df_maxunpool2x2(const float *x, const unsigned char *idx, float *y, int B, int H, int W, int C, df_stream_t stream);
 int df_maxpool3s2_bwd(const float *x, const float *dy, float *dx, int B, int H, int W, int C, int OH, int OW, df_stream_t stream);
 int df_adaptive_avgpool(const float *in, float *out, int B, int H, int W, int C, int s, int backward, df_stream_t stream);
 int df_bilinear(const float *in, float *out, int B, int H, int W, int C, int OH, int OW, int align_corners, int backward,

@@ -201,6 +201,29 @@ def run_ply():
     print("ply", pred.shape, tgt.shape)
 
 
+def run_segnet():
+    """vanilla_segmentation/segnet.py imported as it stands (pure torch), seeded synthetic weights incl. BatchNorm running
+    statistics (synth.make_segnet_state_dict, loaded strict=True: proves the key layout), eval-mode logits of a 2 x 3 x 32 x 64
+    normalised image batch."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_segnet", os.path.join(REF, "vanilla_segmentation", "segnet.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    net = mod.SegNet()
+    sd = synth.make_segnet_state_dict(77)
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == synth.segnet_spec()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    net.eval()
+    rng = np.random.Generator(np.random.PCG64(5))
+    mean = np.array([0.485, 0.456, 0.406], dtype=np.float32)[None, :, None, None]
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float32)[None, :, None, None]
+    x = ((rng.integers(0, 256, (2, 3, 32, 64)).astype(np.float32) / 255.0 - mean) / std).astype(np.float32)
+    with torch.no_grad():
+        y = net(torch.from_numpy(x)).numpy()
+    np.savez_compressed(os.path.join(OUT, "segnet_small.npz"), x=x, logits=y.astype(np.float32), meta=np.array([77, 5]))
+    print("segnet", y.shape)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -215,6 +238,8 @@ def main():
         run_quat(ref)
     if not only or "ply" in only:
         run_ply()
+    if not only or "segnet" in only:
+        run_segnet()
 
 
 if __name__ == "__main__":

@@ -133,3 +133,17 @@ def test_shipped_ply_clouds_add_and_adds(golden_dir):
     assert abs(add - 0.0168566) < 1e-6
     assert abs(adds - 0.0092865) < 1e-6
     assert abs(adds_rev - 0.0095001) < 1e-6
+
+
+def test_segnet_restatement_matches_reference_golden():
+    """oracle/segnet_ref.py vs the logits of the imported vanilla_segmentation/segnet.py (tests/golden/segnet_small.npz)."""
+    import torch
+    from densefusion_amd import synth
+    from oracle import segnet_ref
+    g = np.load(os.path.join(G, "segnet_small.npz"))
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_segnet_state_dict(int(g["meta"][0])).items()}
+    assert len(synth.segnet_spec()) == 26 * 2 + 25 * 5
+    with torch.no_grad():
+        y = segnet_ref.segnet_forward(sd, torch.from_numpy(g["x"])).numpy()
+    assert y.shape == (2, 22, 32, 64)
+    assert np.abs(y - g["logits"]).max() <= 1e-5 * np.abs(g["logits"]).max()
