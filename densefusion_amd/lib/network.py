@@ -17,7 +17,6 @@ kernels, autograd as the tape, Dropout2d active), one object per call like the r
 """
 from __future__ import annotations
 
-import ctypes
 import math
 
 import torch

@@ -13,8 +13,6 @@ conv + bias + ReLU as one launch of the fp32-MFMA kernel (the >= 256-channel lay
 """
 from __future__ import annotations
 
-import ctypes
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F

@@ -9,7 +9,6 @@ That is what the symmetric branch below implements, through oracle/knn_ref.c.
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
 
 from .knn import knn_ref

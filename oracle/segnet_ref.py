@@ -7,7 +7,6 @@ reference module (tests/golden/segnet_small.npz, oracle/make_golden.py).
 """
 from __future__ import annotations
 
-import torch
 import torch.nn.functional as F
 
 _ENC_BLOCKS = [["11", "12"], ["21", "22"], ["31", "32", "33"], ["41", "42", "43"], ["51", "52", "53"]]

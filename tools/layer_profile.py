@@ -1,5 +1,5 @@
 """Dev tool: per-GEMM-launch time / TFLOP/s of one batched bucket (DF_PROFILE_VERBOSE dump)."""
-import os, sys, ctypes
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["DF_PROFILE_VERBOSE"] = "1"
 import torch
