@@ -59,14 +59,18 @@ def build_parser():
 
 def main(argv=None):
     opt = build_parser().parse_args(argv)
-    dev = torch.device("cuda")
+    # frames shard over the GPUs of a node without any collective: under `python -m torch.distributed.run --nproc-per-node N`
+    # rank r takes the keyframes r, r + N, ... and writes their result files (every frame is independent)
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     estimator = PoseNet(num_points=opt.num_points, num_obj=opt.num_obj)
-    estimator.cuda()
-    estimator.load_state_dict(torch.load(opt.model, map_location="cuda", weights_only=True))
+    estimator.to(dev)
+    estimator.load_state_dict(torch.load(opt.model, map_location=dev, weights_only=True))
     estimator.eval()
     refiner = PoseRefineNet(num_points=opt.num_points, num_obj=opt.num_obj)
-    refiner.cuda()
-    refiner.load_state_dict(torch.load(opt.refine_model, map_location="cuda", weights_only=True))
+    refiner.to(dev)
+    refiner.load_state_dict(torch.load(opt.refine_model, map_location=dev, weights_only=True))
     refiner.eval()
     pe = PoseEstimator(estimator, refiner)
 
@@ -78,6 +82,8 @@ def main(argv=None):
     os.makedirs(opt.result_refine_dir, exist_ok=True)
 
     for now, rel in enumerate(testlist):
+        if now % world != rank:
+            continue
         rgb = np.array(Image.open("{0}/{1}-color.png".format(opt.dataset_root, rel)))[:, :, :3]
         depth = np.array(Image.open("{0}/{1}-depth.png".format(opt.dataset_root, rel))).astype(np.uint16)
         meta = scio.loadmat("{0}/results_PoseCNN_RSS2018/{1}.mat".format(opt.ycb_toolbox_dir, "%06d" % now))
