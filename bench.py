@@ -76,49 +76,87 @@ def make_buckets(rank, world, per_bucket, device):
     return buckets
 
 
-def run_step(pe, buckets, streams=None):
-    """One pass over all buckets.  With `streams`, every bucket runs on its own HIP stream (forked from and
-    joined back into the current stream) so that the small launches of the small crops overlap with the
-    others; each bucket then needs its own workspace, i.e. its own PoseEstimator (`pe` is a list)."""
+def make_groups(buckets, G, device):
+    """Split every crop-size bucket into G equal parts; group g = part g of every bucket = one df_estimate_poses_multi call
+    (objects concatenated in bucket order).  G = 0: one group per crop size (the per-bucket launch sequences of round 1)."""
+    groups = []
+    if G <= 0:
+        parts = [[(bi, 0, b["img"].shape[0])] for bi, b in enumerate(buckets)]
+    else:
+        parts = []
+        for g in range(G):
+            part = []
+            for bi, b in enumerate(buckets):
+                n = b["img"].shape[0]
+                lo, hi = g * n // G, (g + 1) * n // G
+                if hi > lo:
+                    part.append((bi, lo, hi))
+            parts.append(part)
+    for part in parts:
+        cat = lambda k: torch.cat([buckets[bi][k][lo:hi] for bi, lo, hi in part]).contiguous()
+        n = sum(hi - lo for _, lo, hi in part)
+        groups.append(dict(part=part, imgs=[buckets[bi]["img"][lo:hi] for bi, lo, hi in part], cloud=cat("cloud"),
+                           choose=cat("choose").reshape(n, -1), obj=cat("obj").reshape(n),
+                           out=(torch.empty(n, 7, dtype=torch.float64, device=device), torch.empty(n, 7, dtype=torch.float64, device=device))))
+    return groups
+
+
+def run_step(pe, groups, streams=None):
+    """One pass over all groups.  With `streams`, every group runs on its own HIP stream (forked from and joined back into the
+    current stream) so that one group's memory-bound glue kernels overlap with another's GEMMs; each group has its own
+    workspace, i.e. its own PoseEstimator."""
     if streams is None:
-        for b in buckets:
-            pe[0].estimate(b["img"], b["cloud"], b["choose"], b["obj"], ITERS, out=b["out"])
+        for i, g in enumerate(groups):
+            pe[i].estimate_multi(g["imgs"], g["cloud"], g["choose"], g["obj"], ITERS, out=g["out"])
         return
     main = torch.cuda.current_stream()
-    for i in reversed(range(len(buckets))):          # largest crop first
-        b, st = buckets[i], streams[i]
+    for i in reversed(range(len(groups))):
+        g, st = groups[i], streams[i]
         st.wait_stream(main)
         with torch.cuda.stream(st):
-            pe[i].estimate(b["img"], b["cloud"], b["choose"], b["obj"], ITERS, out=b["out"])
+            pe[i].estimate_multi(g["imgs"], g["cloud"], g["choose"], g["obj"], ITERS, out=g["out"])
     for st in streams:
         main.wait_stream(st)
 
 
-def profile_gemm(pe, buckets, steps):
+def bucket_poses(buckets, groups):
+    """final poses per crop-size bucket (host), reassembled from the groups' outputs"""
+    out = [np.zeros((b["img"].shape[0], 7)) for b in buckets]
+    for g in groups:
+        p = g["out"][1].cpu().numpy()
+        o = 0
+        for bi, lo, hi in g["part"]:
+            out[bi][lo:hi] = p[o:o + hi - lo]
+            o += hi - lo
+    return out
+
+
+def profile_gemm(pe, groups, steps):
+    """Instrumented SERIAL re-run (one stream, no graph): HIP events around every GEMM launch on the launch stream."""
     L = _lib.lib()
     hp, hr = pe[0].estimator._handle, pe[0].refiner._handle
     L.df_net_profile(hp, 1); L.df_net_profile(hr, 1)
-    tot_ms = tot_fl = tot_by = 0.0
+    tot = np.zeros(4)
     tot_n = 0
     for _ in range(steps):
-        run_step(pe, buckets)
+        run_step(pe, groups)
         torch.cuda.synchronize()
         for h in (hp, hr):
-            ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-            _lib.check(L.df_net_profile_read(h, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n)), "profile_read")
-            tot_ms += ms.value; tot_fl += fl.value; tot_by += by.value; tot_n += n.value
+            ms, fl, us, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+            _lib.check(L.df_net_profile_read(h, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(us), ctypes.byref(by), ctypes.byref(n)), "profile_read")
+            tot += (ms.value, fl.value, us.value, by.value); tot_n += n.value
     L.df_net_profile(hp, 0); L.df_net_profile(hr, 0)
-    return tot_ms, tot_fl, tot_by, tot_n
+    return tot[0], tot[1], tot[2], tot[3], tot_n
 
 
 def measured_traffic():
     """HBM bytes per igemm launch from the committed PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE,
-    profiles/r01_igemm_traffic.json); None when the file is absent."""
+    profiles/r02_igemm_traffic.json); None when the file is absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_igemm_traffic.json")) as f:
             t = json.load(f)
         per = t["hbm_bytes_corrected_per_dispatch"]["total"] if "hbm_bytes_corrected_per_dispatch" in t else t["avg_hbm_bytes_per_launch"]
-        return {"hbm_mb_per_launch": round(per / 1e6, 2), "source": "profiles/r01_igemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+        return {"hbm_mb_per_launch": round(per / 1e6, 2), "source": "profiles/r02_igemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
                 "separate passes, serial un-graphed run of this workload; tools/make_profiles.sh)"}
     except Exception:   # noqa: BLE001
         return None
@@ -282,7 +320,10 @@ def main():
     ap.add_argument("--per-bucket", type=int, default=40, help="objects of each crop size per step and GPU")
     ap.add_argument("--refine-iters", type=int, default=ITERS, help="refine iterations per pose (metric: 2; BASELINE configs[2] as written: 4)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-streams", action="store_true", help="run the crop-size buckets back to back on one stream")
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("DF_BENCH_GROUPS", "2")),
+                    help="split the step's objects into this many multi-bucket calls, one HIP stream each (0: one call per crop size, "
+                         "the round-1 launch structure)")
+    ap.add_argument("--no-streams", action="store_true", help="run the groups back to back on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse "
@@ -308,22 +349,23 @@ def main():
 
     est, ref = load_nets(device)
     buckets = make_buckets(rank, world, args.per_bucket, device)
-    pe = [PoseEstimator(est, ref) for _ in buckets]         # one workspace per bucket (they may run concurrently)
-    streams = None if args.no_streams else [torch.cuda.Stream() for _ in buckets]
+    groups = make_groups(buckets, args.groups, device)
+    pe = [PoseEstimator(est, ref) for _ in groups]          # one workspace per group (they may run concurrently)
+    streams = None if (args.no_streams or len(groups) == 1) else [torch.cuda.Stream() for _ in groups]
     poses_per_step = args.per_bucket * len(CROPS)
     gdev = device if args.backend == "nccl" else torch.device("cpu")
     gathered = [torch.empty(poses_per_step, 7, dtype=torch.float64, device=gdev) for _ in range(world)] if world > 1 else None
 
     def gather():      # results to every rank: the only communication of the inference path (a few KB per step)
-        mine = torch.cat([b["out"][1] for b in buckets])
+        mine = torch.cat([g["out"][1] for g in groups])
         dist.all_gather(gathered, mine if args.backend == "nccl" else mine.cpu())
 
     def step():
-        run_step(pe, buckets, streams)
+        run_step(pe, groups, streams)
         if world > 1:
             gather()
 
-    run_step(pe, buckets)                      # eager pass: uploads weights, sizes the workspace
+    run_step(pe, groups)                       # eager pass: uploads weights, sizes the workspace
     torch.cuda.synchronize()
     graph = None
     if not args.no_graph:
@@ -331,11 +373,11 @@ def main():
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                run_step(pe, buckets, streams)
+                run_step(pe, groups, streams)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime
-                run_step(pe, buckets, streams)
+                run_step(pe, groups, streams)
         except Exception as e:                 # noqa: BLE001
             print(f"[bench] hipGraph capture failed ({e}); running eagerly", file=sys.stderr)
             graph = None
@@ -378,18 +420,20 @@ def main():
                                    "K=21 objects, N=1000 points, crops cycled over 80x80..240x320, 5 objects/frame)",
                        "num_obj": K_OBJ, "num_points": N_PTS, "refine_iters": ITERS, "crops": CROPS,
                        "objects_per_step_per_gpu": poses_per_step, "frames_per_step_per_gpu": poses_per_step / 5,
-                       "hipgraph": graph is not None, "bucket_streams": streams is not None, "sharding": f"objects round-robin over {world} rank(s), no data-path collective",
+                       "hipgraph": graph is not None, "groups": len(groups), "group_streams": streams is not None, "sharding": f"objects round-robin over {world} rank(s), no data-path collective",
                        "reference_algorithm_gflop_per_step_per_gpu": round(gflop_step, 1),
                        "note": "reference_algorithm_* counts the FLOPs of the reference's own layer graph (SURVEY 8d); this build "
                                "executes fewer (PSP fold, low-resolution up-convs, Winograd-domain trunk, chosen-pixel up_3, confidence-first heads: DESIGN.md 5), so that rate may exceed the fp32 peak"},
             "reference_algorithm_tflops_per_gpu": round(gflop_step * args.steps / dt / 1e3, 2),
         }
-        ms, fl, by, n = profile_gemm(pe, buckets, min(args.steps, 5))
+        ms, fl, useful, by, n = profile_gemm(pe, groups, min(args.steps, 5))
         traffic = measured_traffic()
         ach = fl / ms / 1e9 if ms > 0 else 0.0
         out["roofline"] = {"kernel": "igemm_f32_v2_kernel (implicit-GEMM conv / per-point / Winograd-domain GEMM, v_mfma_f32_32x32x2_f32; all launches of a step)",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+                           "frac": round(ach / FP32_PEAK_TFLOPS, 4),
+                           "useful_frac": round(useful / ms / 1e9 / FP32_PEAK_TFLOPS, 4) if ms > 0 else 0.0,
+                           "traffic": traffic,
                            "algorithmic_mb_per_launch": round(by / max(n, 1) / 1e6, 2),
                            "launches_per_step": n // max(1, min(args.steps, 5)),
                            "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
@@ -399,7 +443,7 @@ def main():
             out["knn"] = bench_knn()
             out["latency_single_object"] = bench_latency(est, ref, device)
         if world == 1 and not args.no_cpu_baseline:
-            gpu_poses = [b["out"][1].cpu().numpy() for b in buckets]
+            gpu_poses = bucket_poses(buckets, groups)
             out["cpu_baseline"], out["parity"] = cpu_baseline(buckets, gpu_poses)
         print(json.dumps(out))
     if world > 1:

@@ -40,6 +40,8 @@ SIGNATURES = {
     "df_refiner_forward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "df_estimate_workspace_bytes": (_sz, [_vp, _vp, _i, _i, _i]),
     "df_estimate_poses": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "df_estimate_multi_workspace_bytes": (_sz, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "df_estimate_poses_multi": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "df_loss_forward": (_i, [_vp] * 6 + [_i, _i, _f, _i] + [_vp] * 7),
     "df_loss_refine_forward": (_i, [_vp] * 5 + [_i, _i, _i] + [_vp] * 5),
     "df_loss_backward": (_i, [_vp] * 8 + [_i, _i, _f, _f] + [_vp] * 4),
@@ -67,7 +69,7 @@ SIGNATURES = {
     "df_conv2d_dgrad_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),
     "df_conv2d_wgrad_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "df_net_profile": (_i, [_vp, _i]),
-    "df_net_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i)]),
+    "df_net_profile_read": (_i, [_vp] + [ctypes.POINTER(ctypes.c_double)] * 4 + [ctypes.POINTER(_i)]),
 }
 
 

@@ -41,7 +41,7 @@ struct Net {
   // profiling of GEMM launches (bench.py roofline): event pairs around every launch_conv
   bool profiling = false;
   std::vector<hipEvent_t> ev;
-  std::vector<double> ev_flops, ev_bytes;
+  std::vector<double> ev_flops, ev_bytes, ev_useful;
   std::vector<std::string> ev_desc;
   size_t ev_used = 0;
 };
@@ -319,7 +319,11 @@ struct Ctx {
     }
     return it->second;
   }
-  void conv(const ConvParams &p) {
+  // `useful`: the fraction of the launch's rows that are not padding (points beyond N in a 128-padded object block, Winograd
+  // tiles beyond the map edge) -- only for the profile's useful-FLOP tally
+  double pt_useful = 1.0;      // N / Npad of the per-point launches
+  void pconv(const ConvParams &p) { conv(p, pt_useful); }
+  void conv(const ConvParams &p, double useful = 1.0) {
     if (!live()) return;
     Net &n = *net;
     if (n.profiling) {
@@ -335,6 +339,7 @@ struct Ctx {
       hipEventRecord(n.ev[n.ev_used + 1], st);
       n.ev_flops.push_back(conv_flops(p));
       n.ev_bytes.push_back(conv_bytes(p));
+      n.ev_useful.push_back(conv_flops(p) * useful);
       char d[160];
       snprintf(d, sizeof(d), "M=%ld N=%d K=%d k%dx%d s%d d%d z%d", (long)p.B * p.OH * p.OW, p.Cout, p.KH * p.KW * p.Cin, p.KH,
                p.KW, p.stride, p.dil, p.zcount);
@@ -399,92 +404,160 @@ struct PoseNetOut {
   float *emb_pm = nullptr;              // [B][Npad][32] inside the workspace
 };
 
-// PSPNet colour branch + gather: lib/pspnet.py:64-77 on top of lib/extractors.py:114-124
-static float *cnn_forward(Ctx &c, int B, int H, int W, const float *img, int &outH, int &outW) {
-  const std::string P = CNN;
-  float *img4 = c.f((size_t)B * H * W * 4);
-  if (c.live()) launch_nchw3_to_nhwc4(img, img4, B, H, W, c.st);
-  const int H1 = conv_out(H, 7, 2, 3, 1), W1 = conv_out(W, 7, 2, 3, 1);
-  float *stem = c.f((size_t)B * H1 * W1 * 64);
-  c.conv(conv2d(img4, B, H, W, 4, 4, c.w(P + "feats.conv1.weight"), nullptr, stem, H1, W1, 64, 64, 0, 7, 2, 3, 1, ACT_RELU));
-  const int H2 = conv_out(H1, 3, 2, 1, 1), W2 = conv_out(W1, 3, 2, 1, 1);
-  float *x = c.f((size_t)B * H2 * W2 * 64);
-  if (c.live()) launch_maxpool3s2(stem, x, B, H1, W1, 64, H2, W2, c.st);
+// One crop-size bucket of a call: B same-sized objects.  A call evaluates a list of buckets: every launch whose arithmetic does
+// not depend on the crop geometry (1x1 convs, the Winograd-domain products, the low-resolution up-conv products and the whole
+// per-point part) runs ONCE over the rows of all buckets; only the direct kxk convolutions and the memory-bound glue kernels
+// (transforms, pooling, interpolation) are launched per bucket, writing into / reading from the shared row-concatenated buffers.
+struct Grp { int B, H, W; const float *img; };
 
-  int h = H2, w = W2, cin = 64, x_ld = 64;
-  const int planes_of[4] = {64, 128, 256, 512}, stride_of[4] = {1, 2, 1, 1}, dil_of[4] = {1, 1, 2, 4};
-  // conv3x3 (+ residual) + ReLU: direct implicit GEMM, or the Winograd-domain product where the layer geometry pays
-  auto conv3x3 = [&](const float *in, int ih, int iw, int ci, int in_ld, const std::string &key, float *out, int oh, int ow, int co,
-                     int stride, int dil, const float *res, int res_ld) {
-    if (wino_enabled() && stride == 1 && wino_pays(ih, iw, dil, ci, co)) {
-      wino_conv(c, in, B, ih, iw, ci, in_ld, key, out, co, co, 0, dil, res, res_ld, ACT_RELU);
-      return;
+// per-bucket map sizes and row offsets of one resolution level of the concatenated activations
+struct Level {
+  std::vector<int> h, w;
+  std::vector<long> off;     // first pixel row of bucket i
+  long rows = 0;
+  void push(int B, int hh, int ww) { h.push_back(hh); w.push_back(ww); off.push_back(rows); rows += (long)B * hh * ww; }
+};
+
+// PSPNet colour branch (lib/pspnet.py:64-77 on top of lib/extractors.py:114-124) up to up_2's output: returns the concatenated
+// half-resolution 64-channel maps and their level
+static float *cnn_forward(Ctx &c, const std::vector<Grp> &gs, Level &half_lv) {
+  const std::string P = CNN;
+  const int nb = (int)gs.size();
+  Level l0, l1;          // stem output, max-pool output
+  for (const Grp &g : gs) {
+    const int H1 = conv_out(g.H, 7, 2, 3, 1), W1 = conv_out(g.W, 7, 2, 3, 1);
+    l0.push(g.B, H1, W1);
+    l1.push(g.B, conv_out(H1, 3, 2, 1, 1), conv_out(W1, 3, 2, 1, 1));
+  }
+  float *x = c.f((size_t)l1.rows * 64);
+  {
+    const size_t mark = c.off;     // img4 / stem are dead after the pooling: their region is reused by the layers below
+    for (int i = 0; i < nb; ++i) {
+      const Grp &g = gs[i];
+      float *img4 = c.f((size_t)g.B * g.H * g.W * 4);
+      if (c.live()) launch_nchw3_to_nhwc4(g.img, img4, g.B, g.H, g.W, c.st);
+      float *stem = c.f((size_t)g.B * l0.h[i] * l0.w[i] * 64);
+      c.conv(conv2d(img4, g.B, g.H, g.W, 4, 4, c.w(P + "feats.conv1.weight"), nullptr, stem, l0.h[i], l0.w[i], 64, 64, 0, 7, 2, 3, 1, ACT_RELU));
+      if (c.live()) launch_maxpool3s2(stem, x + l1.off[i] * 64, g.B, l0.h[i], l0.w[i], 64, l1.h[i], l1.w[i], c.st);
     }
-    ConvParams p = conv2d(in, B, ih, iw, ci, in_ld, c.w(key), nullptr, out, oh, ow, co, co, 0, 3, stride, dil, dil, ACT_RELU);
-    p.res = res; p.res_ld = res_ld;
-    c.conv(p);
+    c.off = mark;
+    (void)mark;
+  }
+
+  // conv3x3 (+ residual) + ReLU over all buckets: buckets whose geometry makes the Winograd-domain product pay share ONE z-batched
+  // GEMM over the concatenation of their tiles (per-bucket transforms around it); the others run the direct implicit GEMM
+  auto conv3x3 = [&](const float *in, const Level &li, int ci, const std::string &key, float *out, const Level &lo, int co, int stride, int dil,
+                     const float *res) {
+    std::vector<int> ws;
+    for (int i = 0; i < nb; ++i) {
+      if (wino_enabled() && stride == 1 && wino_pays(li.h[i], li.w[i], dil, ci, co)) { ws.push_back(i); continue; }
+      ConvParams p = conv2d(in + li.off[i] * ci, gs[i].B, li.h[i], li.w[i], ci, ci, c.w(key), nullptr, out + lo.off[i] * co, lo.h[i], lo.w[i], co,
+                            co, 0, 3, stride, dil, dil, ACT_RELU);
+      if (res) { p.res = res + lo.off[i] * co; p.res_ld = co; }
+      c.conv(p);
+    }
+    if (ws.empty()) return;
+    std::vector<long> t0;
+    long T = 0;
+    for (int i : ws) { t0.push_back(T); T += wino_geom(gs[i].B, li.h[i], li.w[i], dil).T; }
+    const size_t mark = c.off;       // V / M are scratch: consecutive layers reuse the same region
+    float *V = c.f((size_t)16 * T * ci), *M = c.f((size_t)16 * T * co);
+    for (size_t j = 0; j < ws.size(); ++j) {
+      const int i = ws[j];
+      if (c.live()) launch_wino_input(in + li.off[i] * ci, ci, 0, V, gs[i].B, li.h[i], li.w[i], ci, dil, c.st, T, t0[j]);
+    }
+    ConvParams p = point_gemm(V, ci, 0, ci, c.w(key + ".wino"), nullptr, M, co, 0, co, (int)T, ACT_NONE);
+    p.zcount = 16; p.z_in_coff = T * ci; p.z_wgt = (long)co * ci; p.z_out_coff = T * co;
+    double px = 0;        // output pixels the tiles are for: a tile yields 2x2 of them
+    for (int i : ws) px += (double)gs[i].B * li.h[i] * li.w[i];
+    c.conv(p, px / (4.0 * (double)T));
+    for (size_t j = 0; j < ws.size(); ++j) {
+      const int i = ws[j];
+      if (c.live())
+        launch_wino_output(M, out + lo.off[i] * co, co, 0, nullptr, res ? res + lo.off[i] * co : nullptr, co, 0, ACT_RELU, gs[i].B, li.h[i], li.w[i], co,
+                           dil, c.st, T, t0[j]);
+    }
+    c.off = mark;
   };
+
+  Level lx = l1;
+  int cin = 64;
+  const int planes_of[4] = {64, 128, 256, 512}, stride_of[4] = {1, 2, 1, 1}, dil_of[4] = {1, 1, 2, 4};
   for (int li = 1; li <= 4; ++li) {
     const int planes = planes_of[li - 1], s = stride_of[li - 1], d = dil_of[li - 1];
     const std::string base = P + "feats.layer" + std::to_string(li) + ".";
+    Level lo;
+    for (int i = 0; i < nb; ++i) lo.push(gs[i].B, conv_out(lx.h[i], 3, s, 1, 1), conv_out(lx.w[i], 3, s, 1, 1));
     // block 0: built without dilation (lib/extractors.py:107); carries the stride and the 1x1 downsample
-    const int oh = conv_out(h, 3, s, 1, 1), ow = conv_out(w, 3, s, 1, 1);
-    float *t = c.f((size_t)B * oh * ow * planes);
-    conv3x3(x, h, w, cin, x_ld, base + "0.conv1.weight", t, oh, ow, planes, s, 1, nullptr, 0);
+    float *t = c.f((size_t)lo.rows * planes);
+    conv3x3(x, lx, cin, base + "0.conv1.weight", t, lo, planes, s, 1, nullptr);
     const float *res = x;
-    int res_ld = x_ld;
     if (cin != planes || s != 1) {
-      float *ds = c.f((size_t)B * oh * ow * planes);
-      c.conv(conv2d(x, B, h, w, cin, x_ld, c.w(base + "0.downsample.0.weight"), nullptr, ds, oh, ow, planes, planes, 0, 1, s, 0, 1, ACT_NONE));
+      float *ds = c.f((size_t)lo.rows * planes);
+      if (s == 1) {     // a 1x1 stride-1 conv is a plain GEMM over pixel rows: one launch for all buckets
+        c.conv(point_gemm(x, cin, 0, cin, c.w(base + "0.downsample.0.weight"), nullptr, ds, planes, 0, planes, (int)lo.rows, ACT_NONE));
+      } else {
+        for (int i = 0; i < nb; ++i)
+          c.conv(conv2d(x + lx.off[i] * cin, gs[i].B, lx.h[i], lx.w[i], cin, cin, c.w(base + "0.downsample.0.weight"), nullptr, ds + lo.off[i] * planes,
+                        lo.h[i], lo.w[i], planes, planes, 0, 1, s, 0, 1, ACT_NONE));
+      }
       res = ds;
-      res_ld = planes;
     }
-    float *o0 = c.f((size_t)B * oh * ow * planes);
-    conv3x3(t, oh, ow, planes, planes, base + "0.conv2.weight", o0, oh, ow, planes, 1, 1, res, res_ld);
+    float *o0 = c.f((size_t)lo.rows * planes);
+    conv3x3(t, lo, planes, base + "0.conv2.weight", o0, lo, planes, 1, 1, res);
     // block 1: dilated (lib/extractors.py:110)
-    float *t1 = c.f((size_t)B * oh * ow * planes);
-    conv3x3(o0, oh, ow, planes, planes, base + "1.conv1.weight", t1, oh, ow, planes, 1, d, nullptr, 0);
-    float *o1 = c.f((size_t)B * oh * ow * planes);
-    conv3x3(t1, oh, ow, planes, planes, base + "1.conv2.weight", o1, oh, ow, planes, 1, d, o0, planes);
-    x = o1; x_ld = planes; h = oh; w = ow; cin = planes;
+    float *t1 = c.f((size_t)lo.rows * planes);
+    conv3x3(o0, lo, planes, base + "1.conv1.weight", t1, lo, planes, 1, d, nullptr);
+    float *o1 = c.f((size_t)lo.rows * planes);
+    conv3x3(t1, lo, planes, base + "1.conv2.weight", o1, lo, planes, 1, d, o0);
+    x = o1; lx = lo; cin = planes;
   }
   // PSP module (lib/pspnet.py:20-24) with the bottleneck folded through the pyramid:
   //   bottleneck(cat(up(W_s pool_s(f)), f)) = W_b[:,2048:] f + sum_s up((W_b[:,512s:512s+512] W_s) pool_s(f)) + b
   // (1x1 convs and bilinear resampling are linear and commute), so the 2560-channel concat is never built,
   // the big GEMM shrinks from K=2560 to K=512 and the four stage convs become one grouped launch on
   // 50 pooled rows per object with weights combined once at load time (psp_fold).
-  float *pooled = c.f((size_t)4 * B * 36 * 512), *zst = c.f((size_t)4 * B * 36 * 1024);
-  if (c.live()) launch_psp_pool(x, 512, 0, pooled, B, h, w, 512, c.st);
-  {
+  float *prior = c.f((size_t)lx.rows * 1024);
+  for (int i = 0; i < nb; ++i) {
+    const int B = gs[i].B;
+    float *pooled = c.f((size_t)4 * B * 36 * 512), *zst = c.f((size_t)4 * B * 36 * 1024);
+    if (c.live()) launch_psp_pool(x + lx.off[i] * 512, 512, 0, pooled, B, lx.h[i], lx.w[i], 512, c.st);
     ConvParams p = point_gemm(pooled, 512, 0, 512, c.w("psp.fold.w"), nullptr, zst, 1024, 0, 1024, B * 36, ACT_NONE);
     p.zcount = 4; p.z_in_coff = (long)B * 36 * 512; p.z_wgt = 1024 * 512; p.z_out_coff = (long)B * 36 * 1024;
     c.conv(p);
+    if (c.live()) launch_psp_prior_sum(zst, prior + lx.off[i] * 1024, B, lx.h[i], lx.w[i], 1024, c.st);
   }
-  float *prior = c.f((size_t)B * h * w * 1024);
-  if (c.live()) launch_psp_prior_sum(zst, prior, B, h, w, 1024, c.st);
-  float *psp = c.f((size_t)B * h * w * 1024);
+  float *psp = c.f((size_t)lx.rows * 1024);
   {
-    ConvParams p = point_gemm(x, 512, 0, 512, c.w("psp.fold.wfeat"), c.w(P + "psp.bottleneck.bias"), psp, 1024, 0, 1024, B * h * w, ACT_RELU);
+    ConvParams p = point_gemm(x, 512, 0, 512, c.w("psp.fold.wfeat"), c.w(P + "psp.bottleneck.bias"), psp, 1024, 0, 1024, (int)lx.rows, ACT_RELU);
     p.res = prior; p.res_ld = 1024;
     c.conv(p);
   }
   // PSPUpsample stages up_1, up_2 (lib/pspnet.py:27-37,69-73; dropout = identity in eval), each as a low-resolution
-  // GEMM with N = 9*Cout followed by the 9-tap interpolation (layers.hip).  up_3 is NOT run here: its output is read
-  // at the chosen pixels only, so the caller evaluates it there (posenet_forward) from the map returned: [B][h][w][64].
+  // GEMM with N = 9*Cout (one launch for all buckets) followed by the per-bucket 9-tap interpolation (layers.hip).  up_3 is NOT run
+  // here: its output is read at the chosen pixels only, so the caller evaluates it there from the maps returned: [B][h][w][64].
   float *cur = psp;
   const char *ups[2] = {"up_1", "up_2"};
   const int up_in[2] = {1024, 256}, up_out[2] = {256, 64};
   for (int u = 0; u < 2; ++u) {
-    float *y = c.f((size_t)B * h * w * 9 * up_out[u]);
-    c.conv(point_gemm(cur, up_in[u], 0, up_in[u], c.w(P + ups[u] + ".conv.1.weight.tm"), nullptr, y, 9 * up_out[u], 0, 9 * up_out[u],
-                      B * h * w, ACT_NONE));
-    float *o = c.f((size_t)B * 4 * h * w * up_out[u]);
-    if (c.live())
-      launch_upconv_gather(y, c.w(P + ups[u] + ".conv.1.bias"), c.w(P + ups[u] + ".conv.2.weight"), o, B, h, w, up_out[u], c.st);
-    h *= 2; w *= 2;
+    const size_t mark = c.off;
+    float *o = c.f((size_t)4 * lx.rows * up_out[u]);
+    const size_t keep = c.off;
+    float *y = c.f((size_t)lx.rows * 9 * up_out[u]);
+    c.conv(point_gemm(cur, up_in[u], 0, up_in[u], c.w(P + ups[u] + ".conv.1.weight.tm"), nullptr, y, 9 * up_out[u], 0, 9 * up_out[u], (int)lx.rows,
+                      ACT_NONE));
+    Level lo;
+    for (int i = 0; i < nb; ++i) lo.push(gs[i].B, 2 * lx.h[i], 2 * lx.w[i]);
+    for (int i = 0; i < nb; ++i)
+      if (c.live())
+        launch_upconv_gather(y + lx.off[i] * 9 * up_out[u], c.w(P + ups[u] + ".conv.1.bias"), c.w(P + ups[u] + ".conv.2.weight"),
+                             o + lo.off[i] * up_out[u], gs[i].B, lx.h[i], lx.w[i], up_out[u], c.st);
+    c.off = keep;        // the tap products are dead once interpolated
+    (void)mark;
+    lx = lo;
     cur = o;
   }
-  outH = h; outW = w;
+  half_lv = lx;
   return cur;
 }
 
@@ -499,11 +572,11 @@ static void posenet_points(Ctx &c, int B, int N, int Npad, const float *cloud, c
   const int rows = B * Npad;
   float *pf = c.f((size_t)rows * 384);          // [x1 64 | e1 64 | x2 128 | e2 128] = pointfeat_1 | pointfeat_2
   if (c.live()) launch_cloud_conv1(cloud, nullptr, c.w("feat.conv1.weight"), c.w("feat.conv1.bias"), pf, 384, B, N, Npad, c.st);
-  c.conv(point_gemm(emb_pm, 32, 0, 32, c.w("feat.e_conv1.weight"), c.w("feat.e_conv1.bias"), pf, 384, 64, 64, rows, ACT_RELU));
-  c.conv(point_gemm(pf, 384, 0, 64, c.w("feat.conv2.weight"), c.w("feat.conv2.bias"), pf, 384, 128, 128, rows, ACT_RELU));
-  c.conv(point_gemm(pf, 384, 64, 64, c.w("feat.e_conv2.weight"), c.w("feat.e_conv2.bias"), pf, 384, 256, 128, rows, ACT_RELU));
+  c.pconv(point_gemm(emb_pm, 32, 0, 32, c.w("feat.e_conv1.weight"), c.w("feat.e_conv1.bias"), pf, 384, 64, 64, rows, ACT_RELU));
+  c.pconv(point_gemm(pf, 384, 0, 64, c.w("feat.conv2.weight"), c.w("feat.conv2.bias"), pf, 384, 128, 128, rows, ACT_RELU));
+  c.pconv(point_gemm(pf, 384, 64, 64, c.w("feat.e_conv2.weight"), c.w("feat.e_conv2.bias"), pf, 384, 256, 128, rows, ACT_RELU));
   float *x5 = c.f((size_t)rows * 512);
-  c.conv(point_gemm(pf, 384, 128, 256, c.w("feat.conv5.weight"), c.w("feat.conv5.bias"), x5, 512, 0, 512, rows, ACT_RELU));
+  c.pconv(point_gemm(pf, 384, 128, 256, c.w("feat.conv5.weight"), c.w("feat.conv5.bias"), x5, 512, 0, 512, rows, ACT_RELU));
   // conv6 + ReLU + AvgPool1d(N): the 1024-wide activation is consumed only by the mean, so it never
   // leaves the GEMM's registers -- per-wave column sums, then a tiny deterministic reduction
   ConvParams p6 = point_gemm(x5, 512, 0, 512, c.w("feat.conv6.weight"), c.w("feat.conv6.bias"), nullptr, 1024, 0, 1024, rows, ACT_RELU);
@@ -511,7 +584,7 @@ static void posenet_points(Ctx &c, int B, int N, int Npad, const float *cloud, c
   const int prow = conv_colsum_rows(p6);
   float *partial = c.f((size_t)prow * 1024);
   p6.colsum = partial;
-  c.conv(p6);
+  c.pconv(p6);
   float *apx = c.f((size_t)B * 1024);
   if (c.live()) launch_colsum_finish(partial, prow / B, apx, B, 1024, N, c.st);
   // head layer 1: W[:, :384] . pointfeat + (W[:, 384:] . ap_x + b) -- the 1024 broadcast channels of the
@@ -525,10 +598,10 @@ static void posenet_points(Ctx &c, int B, int N, int Npad, const float *cloud, c
     {
       ConvParams p = point_gemm(pf, 384, 0, 384, c.dry ? nullptr : w1 + (size_t)2 * 640 * 384, c.dry ? nullptr : gbias + 1280, h1c, 640, 0, 640, rows, ACT_RELU);
       p.rows_per_group = Npad; p.rows_valid = N; p.bias_group_ld = 1920;
-      c.conv(p);
+      c.pconv(p);
     }
-    c.conv(point_gemm(h1c, 640, 0, 640, c.dry ? nullptr : w2 + (size_t)2 * 256 * 640, c.dry ? nullptr : b2 + 512, h2c, 256, 0, 256, rows, ACT_RELU));
-    c.conv(point_gemm(h2c, 256, 0, 256, c.dry ? nullptr : w3 + (size_t)2 * 128 * 256, c.dry ? nullptr : b3 + 256, h3c, 128, 0, 128, rows, ACT_RELU));
+    c.pconv(point_gemm(h1c, 640, 0, 640, c.dry ? nullptr : w2 + (size_t)2 * 256 * 640, c.dry ? nullptr : b2 + 512, h2c, 256, 0, 256, rows, ACT_RELU));
+    c.pconv(point_gemm(h2c, 256, 0, 256, c.dry ? nullptr : w3 + (size_t)2 * 128 * 256, c.dry ? nullptr : b3 + 256, h3c, 128, 0, 128, rows, ACT_RELU));
     if (c.live())
       launch_head_select(h3c, c.w("conv4_c.weight"), c.w("conv4_c.bias"), pf, gbias, w1, w2, b2, w3, b3, c.w("conv4_r.weight"),
                          c.w("conv4_r.bias"), c.w("conv4_t.weight"), c.w("conv4_t.bias"), obj, n.num_obj, cloud, B, N, Npad, conf, sel->pose_wo,
@@ -539,38 +612,48 @@ static void posenet_points(Ctx &c, int B, int N, int Npad, const float *cloud, c
   {
     ConvParams p = point_gemm(pf, 384, 0, 384, c.w("head1.wpt"), gbias, h1, 1920, 0, 1920, rows, ACT_RELU);
     p.rows_per_group = Npad; p.rows_valid = N; p.bias_group_ld = 1920;
-    c.conv(p);
+    c.pconv(p);
   }
   float *h2 = c.f((size_t)rows * 768), *h3 = c.f((size_t)rows * 384);
   {
     ConvParams p = point_gemm(h1, 1920, 0, 640, c.w("head2.w"), c.w("head2.bias"), h2, 768, 0, 256, rows, ACT_RELU);
     p.zcount = 3; p.z_in_coff = 640; p.z_wgt = 256 * 640; p.z_bias = 256; p.z_out_coff = 256;
-    c.conv(p);
+    c.pconv(p);
   }
   {
     ConvParams p = point_gemm(h2, 768, 0, 256, c.w("head3.w"), c.w("head3.bias"), h3, 384, 0, 128, rows, ACT_RELU);
     p.zcount = 3; p.z_in_coff = 256; p.z_wgt = 128 * 256; p.z_bias = 128; p.z_out_coff = 128;
-    c.conv(p);
+    c.pconv(p);
   }
   if (c.live())
     launch_head_final(h3, c.w("conv4_r.weight"), c.w("conv4_r.bias"), c.w("conv4_t.weight"), c.w("conv4_t.bias"),
                       c.w("conv4_c.weight"), c.w("conv4_c.bias"), obj, n.num_obj, out_r, out_t, out_c, B, N, Npad, c.st);
 }
 
-static void posenet_forward(Ctx &c, int B, int H, int W, const float *img, const float *cloud, const int64_t *choose,
-                            const int64_t *obj, PoseNetOut &o, const SelectOut *sel = nullptr) {
+static void posenet_forward(Ctx &c, const std::vector<Grp> &gs, const float *cloud, const int64_t *choose, const int64_t *obj, PoseNetOut &o,
+                            const SelectOut *sel = nullptr) {
   const int N = c.net->num_points, Npad = round_up(N, 128);
-  int fh = 0, fw = 0;
-  float *half = cnn_forward(c, B, H, W, img, fh, fw);     // up_2's output, fh x fw = half resolution, 64 channels
-  // up_3 (bilinear x2 + conv3x3 + PReLU) at the chosen pixels: patch rows, one GEMM with the PReLU fused, then the
-  // final 1x1 conv + LogSoftmax
+  c.pt_useful = (double)N / Npad;
+  int B = 0;
+  for (const Grp &g : gs) B += g.B;
+  Level hl;
+  float *half = cnn_forward(c, gs, hl);     // up_2's outputs: half resolution, 64 channels, buckets concatenated
+  // up_3 (bilinear x2 + conv3x3 + PReLU) at the chosen pixels: patch rows (per bucket: the only geometry-dependent step), then one
+  // GEMM over the points of all objects with the PReLU fused, then the final 1x1 conv + LogSoftmax
   const std::string P = CNN;
   float *patch = c.f((size_t)B * Npad * 576), *z3 = c.f((size_t)B * Npad * 64);
-  if (c.live()) launch_up3_patches(half, choose, patch, B, fh, fw, N, Npad, c.st);
+  {
+    long b0 = 0;
+    for (size_t i = 0; i < gs.size(); ++i) {
+      if (c.live())
+        launch_up3_patches(half + hl.off[i] * 64, choose + b0 * N, patch + (size_t)b0 * Npad * 576, gs[i].B, hl.h[i], hl.w[i], N, Npad, c.st);
+      b0 += gs[i].B;
+    }
+  }
   {
     ConvParams p = point_gemm(patch, 576, 0, 576, c.w(P + "up_3.conv.1.weight"), c.w(P + "up_3.conv.1.bias"), z3, 64, 0, 64, B * Npad, ACT_PRELU);
     p.prelu = c.w(P + "up_3.conv.2.weight");
-    c.conv(p);
+    c.pconv(p);
   }
   o.emb_pm = c.f((size_t)B * Npad * 32);
   if (c.live()) launch_final_logsoftmax(z3, c.w(P + "final.0.weight"), c.w(P + "final.0.bias"), o.emb, o.emb_pm, B, N, Npad, c.st);
@@ -583,6 +666,7 @@ struct RefinerBufs { float *pf, *e5, *x5, *partial, *apx, *f1, *f2; int prow; };
 
 static RefinerBufs refiner_alloc(Ctx &c, int B, int N, int Npad) {
   RefinerBufs r;
+  c.pt_useful = (double)N / Npad;
   const int rows = B * Npad;
   r.pf = c.f((size_t)rows * 384);
   r.e5 = c.f((size_t)rows * 512);
@@ -599,25 +683,25 @@ static RefinerBufs refiner_alloc(Ctx &c, int B, int N, int Npad) {
 
 static void refiner_prepare(Ctx &c, const RefinerBufs &r, int B, int Npad, const float *emb_pm) {
   const int rows = B * Npad;
-  c.conv(point_gemm(emb_pm, 32, 0, 32, c.w("feat.e_conv1.weight"), c.w("feat.e_conv1.bias"), r.pf, 384, 192, 64, rows, ACT_RELU));
-  c.conv(point_gemm(r.pf, 384, 192, 64, c.w("feat.e_conv2.weight"), c.w("feat.e_conv2.bias"), r.pf, 384, 256, 128, rows, ACT_RELU));
+  c.pconv(point_gemm(emb_pm, 32, 0, 32, c.w("feat.e_conv1.weight"), c.w("feat.e_conv1.bias"), r.pf, 384, 192, 64, rows, ACT_RELU));
+  c.pconv(point_gemm(r.pf, 384, 192, 64, c.w("feat.e_conv2.weight"), c.w("feat.e_conv2.bias"), r.pf, 384, 256, 128, rows, ACT_RELU));
   // colour half of conv5 (+ its bias), once per object; the iterations add the xyz half and apply the ReLU
-  c.conv(point_gemm(r.pf, 384, 192, 192, c.w("feat.conv5.we"), c.w("feat.conv5.bias"), r.e5, 512, 0, 512, rows, ACT_NONE));
+  c.pconv(point_gemm(r.pf, 384, 192, 192, c.w("feat.conv5.we"), c.w("feat.conv5.bias"), r.e5, 512, 0, 512, rows, ACT_NONE));
 }
 
 static void refiner_iterate(Ctx &c, const RefinerBufs &r, int B, int N, int Npad, const float *cloud, const float *rt,
                             const int64_t *obj, float *out_r, float *out_t, double *state, float *rt_next, double *pose_out) {
   const int rows = B * Npad;
   if (c.live()) launch_cloud_conv1(cloud, rt, c.w("feat.conv1.weight"), c.w("feat.conv1.bias"), r.pf, 384, B, N, Npad, c.st);
-  c.conv(point_gemm(r.pf, 384, 0, 64, c.w("feat.conv2.weight"), c.w("feat.conv2.bias"), r.pf, 384, 64, 128, rows, ACT_RELU));
+  c.pconv(point_gemm(r.pf, 384, 0, 64, c.w("feat.conv2.weight"), c.w("feat.conv2.bias"), r.pf, 384, 64, 128, rows, ACT_RELU));
   {
     ConvParams p = point_gemm(r.pf, 384, 0, 192, c.w("feat.conv5.wx"), nullptr, r.x5, 512, 0, 512, rows, ACT_RELU);
     p.res = r.e5; p.res_ld = 512;
-    c.conv(p);
+    c.pconv(p);
   }
   ConvParams p6 = point_gemm(r.x5, 512, 0, 512, c.w("feat.conv6.weight"), c.w("feat.conv6.bias"), nullptr, 1024, 0, 1024, rows, ACT_RELU);
   p6.rows_per_group = Npad; p6.rows_valid = N; p6.colsum = r.partial;
-  c.conv(p6);
+  c.pconv(p6);
   if (c.live()) launch_colsum_finish(r.partial, r.prow / B, r.apx, B, 1024, N, c.st);
   // FC towers 1024 -> 512 -> 128 for r and t (lib/network.py:191-196): one row per object
   if (c.live()) {
@@ -698,31 +782,37 @@ extern "C" int df_net_profile(df_net *h, int enable) {
   n->ev_used = 0;
   n->ev_flops.clear();
   n->ev_bytes.clear();
+  n->ev_useful.clear();
   n->ev_desc.clear();
   return DF_OK;
 }
 
 // after a stream sync: sum of GEMM launch durations (ms), their algorithmic FLOPs and count since df_net_profile(1)
-extern "C" int df_net_profile_read(df_net *h, double *gemm_ms, double *gemm_flops, double *gemm_bytes, int *launches) {
+extern "C" int df_net_profile_read(df_net *h, double *gemm_ms, double *gemm_flops, double *gemm_useful_flops, double *gemm_bytes,
+                                   int *launches) {
   if (!h) return set_error(DF_ERR_ARG, "profile_read: null handle");
   Net *n = as_net(h);
-  double ms = 0, fl = 0, by = 0;
+  double ms = 0, fl = 0, by = 0, us = 0;
+  static const bool verbose = getenv("DF_PROFILE_VERBOSE") != nullptr;
   for (size_t i = 0; i + 1 < n->ev_used; i += 2) {
     float t = 0;
     if (hipEventElapsedTime(&t, n->ev[i], n->ev[i + 1]) != hipSuccess) return set_error(DF_ERR_LAUNCH, "profile_read: events not complete");
     ms += t;
     fl += n->ev_flops[i / 2];
     by += n->ev_bytes[i / 2];
-    if (getenv("DF_PROFILE_VERBOSE"))
+    us += n->ev_useful[i / 2];
+    if (verbose)
       fprintf(stderr, "[df-gemm] %s  %.1f us  %.1f TFLOP/s\n", n->ev_desc[i / 2].c_str(), t * 1e3, n->ev_flops[i / 2] / t / 1e9);
   }
   if (gemm_ms) *gemm_ms = ms;
   if (gemm_flops) *gemm_flops = fl;
+  if (gemm_useful_flops) *gemm_useful_flops = us;
   if (gemm_bytes) *gemm_bytes = by;
   if (launches) *launches = (int)(n->ev_used / 2);
   n->ev_used = 0;
   n->ev_flops.clear();
   n->ev_bytes.clear();
+  n->ev_useful.clear();
   n->ev_desc.clear();
   return DF_OK;
 }
@@ -733,11 +823,27 @@ static int posenet_args_ok(const Net *n, int B, int H, int W) {
   return DF_OK;
 }
 
+// bucket list of a multi-bucket call (host arrays of nb entries); img may be null (workspace sizing)
+static int make_groups(const Net *n, int nb, const int *B, const int *H, const int *W, const float *const *img, std::vector<Grp> &gs) {
+  if (nb <= 0 || nb > 64 || !B || !H || !W) return set_error(DF_ERR_ARG, "need 1..64 buckets with B / H / W arrays (got nb = %d)", nb);
+  long tot = 0;
+  gs.clear();
+  for (int i = 0; i < nb; ++i) {
+    const int rc = posenet_args_ok(n, B[i], H[i], W[i]);
+    if (rc != DF_OK) return rc;
+    if (img && !img[i]) return set_error(DF_ERR_ARG, "bucket %d: null image pointer", i);
+    gs.push_back(Grp{B[i], H[i], W[i], img ? img[i] : nullptr});
+    tot += B[i];
+  }
+  if (tot > (1 << 20)) return set_error(DF_ERR_ARG, "too many objects in one call (%ld)", tot);
+  return DF_OK;
+}
+
 extern "C" size_t df_posenet_workspace_bytes(const df_net *h, int B, int H, int W) {
   if (posenet_args_ok(as_net(h), B, H, W) != DF_OK) return 0;
   Ctx c{const_cast<Net *>(as_net(h)), nullptr, true, nullptr};
   PoseNetOut o{};
-  posenet_forward(c, B, H, W, nullptr, nullptr, nullptr, nullptr, o);
+  posenet_forward(c, {Grp{B, H, W, nullptr}}, nullptr, nullptr, nullptr, o);
   return c.peak;
 }
 
@@ -752,7 +858,7 @@ extern "C" int df_posenet_forward(df_net *h, int B, int H, int W, const float *i
   c.cap = ws_bytes;
   if (df_posenet_workspace_bytes(h, B, H, W) > ws_bytes) return set_error(DF_ERR_WORKSPACE, "posenet_forward: workspace too small");
   PoseNetOut o{out_r, out_t, out_c, emb};
-  posenet_forward(c, B, H, W, img, cloud, choose, obj, o);
+  posenet_forward(c, {Grp{B, H, W, img}}, cloud, choose, obj, o);
   return finish(c, "posenet_forward");
 }
 
@@ -786,10 +892,12 @@ extern "C" int df_refiner_forward(df_net *h, int B, const float *x, const float 
   return finish(c, "refiner_forward");
 }
 
-// PoseNet -> selection -> `iters` refine passes, entirely on the device
-static void estimate(Ctx &cp, Ctx &cr, int B, int H, int W, const float *img, const float *cloud, const int64_t *choose,
-                     const int64_t *obj, int iters, double *pose_wo, double *pose) {
+// PoseNet -> selection -> `iters` refine passes, entirely on the device, for the objects of all buckets (concatenated in bucket order)
+static void estimate(Ctx &cp, Ctx &cr, const std::vector<Grp> &gs, const float *cloud, const int64_t *choose, const int64_t *obj, int iters,
+                     double *pose_wo, double *pose) {
   const int N = cp.net->num_points, Npad = round_up(N, 128);
+  int B = 0;
+  for (const Grp &g : gs) B += g.B;
   PoseNetOut o{};
   o.emb = cp.f((size_t)B * 32 * N);
   double *state = reinterpret_cast<double *>(cp.bytes((size_t)B * 7 * sizeof(double)));
@@ -797,7 +905,7 @@ static void estimate(Ctx &cp, Ctx &cr, int B, int H, int W, const float *img, co
   // eval_ycb.py:193-203 reads the r / t heads at the arg-max-confidence point only: confidence tower for all points,
   // r / t towers for that one point (posenet_points, `sel`)
   const SelectOut sel{pose_wo, state, rt};
-  posenet_forward(cp, B, H, W, img, cloud, choose, obj, o, &sel);
+  posenet_forward(cp, gs, cloud, choose, obj, o, &sel);
   // the refiner context continues in the same workspace
   cr.off = cp.off;
   cr.peak = cp.peak;
@@ -808,30 +916,49 @@ static void estimate(Ctx &cp, Ctx &cr, int B, int H, int W, const float *img, co
   if (iters == 0 && cp.live() && pose) hipMemcpyAsync(pose, state, (size_t)B * 7 * sizeof(double), hipMemcpyDeviceToDevice, cp.st);
 }
 
-extern "C" size_t df_estimate_workspace_bytes(const df_net *pn, const df_net *rf, int B, int H, int W) {
-  if (posenet_args_ok(as_net(pn), B, H, W) != DF_OK || !rf || as_net(rf)->kind != 1) return 0;
+static int estimate_handles_ok(const df_net *pn, const df_net *rf) {
+  if (!pn || as_net(pn)->kind != 0) return set_error(DF_ERR_ARG, "estimate_poses: not a PoseNet handle");
+  if (!rf || as_net(rf)->kind != 1) return set_error(DF_ERR_ARG, "estimate_poses: not a PoseRefineNet handle");
+  if (as_net(rf)->num_points != as_net(pn)->num_points || as_net(rf)->num_obj != as_net(pn)->num_obj)
+    return set_error(DF_ERR_ARG, "estimate_poses: estimator / refiner disagree on num_points or num_obj");
+  return DF_OK;
+}
+
+extern "C" size_t df_estimate_multi_workspace_bytes(const df_net *pn, const df_net *rf, int nb, const int *B, const int *H, const int *W) {
+  std::vector<Grp> gs;
+  if (estimate_handles_ok(pn, rf) != DF_OK || make_groups(as_net(pn), nb, B, H, W, nullptr, gs) != DF_OK) return 0;
   Ctx cp{const_cast<Net *>(as_net(pn)), nullptr, true, nullptr}, cr{const_cast<Net *>(as_net(rf)), nullptr, true, nullptr};
-  estimate(cp, cr, B, H, W, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr);
+  estimate(cp, cr, gs, nullptr, nullptr, nullptr, 1, nullptr, nullptr);
   return cr.peak;
+}
+
+extern "C" int df_estimate_poses_multi(df_net *pn, df_net *rf, int nb, const int *B, const int *H, const int *W, const float *const *img,
+                                       const float *cloud, const int64_t *choose, const int64_t *obj, int iters, double *pose_wo,
+                                       double *pose, void *ws, size_t ws_bytes, df_stream_t stream) {
+  int rc = estimate_handles_ok(pn, rf);
+  if (rc != DF_OK) return rc;
+  std::vector<Grp> gs;
+  if (!img) return set_error(DF_ERR_ARG, "estimate_poses: null pointer");
+  if ((rc = make_groups(as_net(pn), nb, B, H, W, img, gs)) != DF_OK) return rc;
+  if (iters < 0) return set_error(DF_ERR_ARG, "estimate_poses: iters < 0");
+  if ((rc = check_ready(*as_net(pn))) != DF_OK || (rc = check_ready(*as_net(rf))) != DF_OK) return rc;
+  if (!cloud || !choose || !obj || !pose || !ws) return set_error(DF_ERR_ARG, "estimate_poses: null pointer");
+  if (df_estimate_multi_workspace_bytes(pn, rf, nb, B, H, W) > ws_bytes) return set_error(DF_ERR_WORKSPACE, "estimate_poses: workspace too small");
+  Ctx cp{as_net(pn), to_stream(stream), false, static_cast<char *>(ws)}, cr{as_net(rf), to_stream(stream), false, static_cast<char *>(ws)};
+  cp.cap = cr.cap = ws_bytes;
+  estimate(cp, cr, gs, cloud, choose, obj, iters, pose_wo, pose);
+  if (cp.err != DF_OK) return cp.err;
+  return finish(cr, "estimate_poses");
+}
+
+extern "C" size_t df_estimate_workspace_bytes(const df_net *pn, const df_net *rf, int B, int H, int W) {
+  return df_estimate_multi_workspace_bytes(pn, rf, 1, &B, &H, &W);
 }
 
 extern "C" int df_estimate_poses(df_net *pn, df_net *rf, int B, int H, int W, const float *img, const float *cloud,
                                  const int64_t *choose, const int64_t *obj, int iters, double *pose_wo, double *pose,
                                  void *ws, size_t ws_bytes, df_stream_t stream) {
-  int rc = posenet_args_ok(as_net(pn), B, H, W);
-  if (rc != DF_OK) return rc;
-  if (!rf || as_net(rf)->kind != 1) return set_error(DF_ERR_ARG, "estimate_poses: not a PoseRefineNet handle");
-  if (as_net(rf)->num_points != as_net(pn)->num_points || as_net(rf)->num_obj != as_net(pn)->num_obj)
-    return set_error(DF_ERR_ARG, "estimate_poses: estimator / refiner disagree on num_points or num_obj");
-  if (iters < 0) return set_error(DF_ERR_ARG, "estimate_poses: iters < 0");
-  if ((rc = check_ready(*as_net(pn))) != DF_OK || (rc = check_ready(*as_net(rf))) != DF_OK) return rc;
-  if (!img || !cloud || !choose || !obj || !pose || !ws) return set_error(DF_ERR_ARG, "estimate_poses: null pointer");
-  if (df_estimate_workspace_bytes(pn, rf, B, H, W) > ws_bytes) return set_error(DF_ERR_WORKSPACE, "estimate_poses: workspace too small");
-  Ctx cp{as_net(pn), to_stream(stream), false, static_cast<char *>(ws)}, cr{as_net(rf), to_stream(stream), false, static_cast<char *>(ws)};
-  cp.cap = cr.cap = ws_bytes;
-  estimate(cp, cr, B, H, W, img, cloud, choose, obj, iters, pose_wo, pose);
-  if (cp.err != DF_OK) return cp.err;
-  return finish(cr, "estimate_poses");
+  return df_estimate_poses_multi(pn, rf, 1, &B, &H, &W, &img, cloud, choose, obj, iters, pose_wo, pose, ws, ws_bytes, stream);
 }
 
 static int conv_desc_to_params(const df_conv_desc *d, ConvParams &p, const char *what);

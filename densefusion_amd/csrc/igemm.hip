@@ -23,6 +23,11 @@
 #include "igemm.h"
 #include <algorithm>
 
+// DF_TRACE(i): per-workgroup time stamps for tools/dev/igemm_trace.hip (compiles this file with the hook defined); nothing otherwise
+#ifndef DF_TRACE
+#define DF_TRACE(i)
+#endif
+
 namespace df {
 namespace {
 
@@ -266,11 +271,12 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
   const int out_coff = p.out_coff + (int)(z * p.z_out_coff);
 
   // buffer descriptors (wave-uniform): reads past num_records return 0
-  const unsigned in_bytes = (unsigned)(((size_t)p.B * p.H * p.W * p.in_ld + (size_t)(p.zcount - 1) * p.z_in_coff) * sizeof(float));
-  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, in_bytes, 0x00020000);
+  // (one descriptor per z slice: a z-batched launch may span more than the 4 GB a descriptor can address)
+  const unsigned in_bytes = (unsigned)((size_t)p.B * p.H * p.W * p.in_ld * sizeof(float));
+  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in + (size_t)z * p.z_in_coff), 0, in_bytes, 0x00020000);
   const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wgt + (size_t)z * p.z_wgt), 0,
                                                       (unsigned)((size_t)p.Cout * K * sizeof(float)), 0x00020000);
-  const int in_c0 = p.in_coff + (int)(z * p.z_in_coff);
+  const int in_c0 = p.in_coff;
 
   const int vec = tid % VPR, lrow = tid / VPR;
   int a_iy0[A_ROWS], a_ix0[A_ROWS], a_off[A_ROWS];   // a_off: element offset of (b, iy0, ix0, first channel)
@@ -376,11 +382,13 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
   };
 
   // prologue: tile 0 -> LDS, tile 1 -> registers
+  DF_TRACE(0);
   issue_loads(0);
   write_lds(0);
   issue_loads(1);
   __syncthreads();
   read_frags(0, 0, a0, b0);
+  DF_TRACE(1);
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     // pair pp multiplies out of register set pp&1 while pair pp+1 is read into the other set
@@ -417,6 +425,7 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
     mfma_group(a1[1], b1[1]);
   }
   __syncthreads();                    // the speculative fragment reads above are done before smem is reused
+  DF_TRACE(2);
 
   // ---- epilogue: accumulators -> LDS (per-wave region) -> 16-byte row segments ----
   constexpr int EP_LD = WN + 4;
@@ -442,18 +451,32 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
   if (bias && nok) bv = *reinterpret_cast<const f32x4 *>(bias + n);
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int ps = 0; ps < WM / ERPP; ++ps) {
+  // the residual rows are requested half a wave tile at a time (two trips to memory instead of one per group of rows)
+  constexpr int NPS = WM / ERPP, HPS = NPS / 2;
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+  f32x4 rres[HPS];
+  if (p.res) {
+#pragma unroll
+    for (int q = 0; q < HPS; ++q) {
+      const int m = m0 + wm * WM + (hh * HPS + q) * ERPP + r0;
+      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+      if (nok && m < M) rv = *reinterpret_cast<const f32x4 *>(p.res + (size_t)m * p.res_ld + p.res_coff + n);
+      rres[q] = rv;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < HPS; ++q) {
+    const int ps = hh * HPS + q;
     const int row = ps * ERPP + r0;
     const int m = m0 + wm * WM + row;
     const bool ok = nok && m < M;
     f32x4 v = *reinterpret_cast<const f32x4 *>(ep + row * EP_LD + c4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] += bv[e];
-    if (p.res && ok) {
-      const f32x4 rv = *reinterpret_cast<const f32x4 *>(p.res + (size_t)m * p.res_ld + p.res_coff + n);
+    if (p.res) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += rv[e];
+      for (int e = 0; e < 4; ++e) v[e] += rres[q][e];
     }
     if (p.act == ACT_RELU) {
 #pragma unroll
@@ -469,6 +492,7 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
       for (int e = 0; e < 4; ++e) csum[e] += real ? v[e] : 0.f;
     }
   }
+  }
   if (p.colsum) {
     // lanes with equal (lane % LPR) hold different rows of the same 4 columns: fold them (fixed order)
 #pragma unroll
@@ -478,6 +502,7 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
     if (lane < LPR && nok)
       *reinterpret_cast<f32x4 *>(p.colsum + ((size_t)z * (gridDim.x / tiles_n) * WAVES_M + (size_t)m_tile * WAVES_M + wm) * p.Cout + n) = csum;
   }
+  DF_TRACE(3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -598,9 +623,10 @@ TileCfg pick_cfg(const ConvParams &p) {
     const long rounds = (tiles + 255) / 256;
     return (double)rounds * bm * bn / eff;
   };
-  if (const char *t = getenv("DF_IGEMM_TILE")) {      // dev switch for A/B runs (tools/gemm_ab.py)
-    if (t[0] == 'a') return {128, 128, 2};
-    if (t[0] == 'c') return {64, 64, 2};
+  static const char *const tile_env = getenv("DF_IGEMM_TILE");      // dev switch for A/B runs; read once
+  if (tile_env) {
+    if (tile_env[0] == 'a') return {128, 128, 2};
+    if (tile_env[0] == 'c') return {64, 64, 2};
   }
   // (a 128x64 tile was measured too: never better than 64x64, up to 1.8x worse on small grids)
   const double c128 = cost(128, 128, 1.0), c64 = cost(64, 64, 0.96);
@@ -650,25 +676,27 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
   const long tiles = ((M + c.bm - 1) / c.bm) * ((p.Cout + c.bn - 1) / c.bn);
   dim3 grid((unsigned)tiles, 1, p.zcount);
   const size_t lds = (size_t)2 * (c.bm + c.bn) * LDK * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {   // 72 KiB of dynamic LDS for the 128x128 tile: above the 64 KiB default cap
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_f32_kernel<128, 128, 2, 2>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * LDK * (int)sizeof(float));
-    attr_done = true;
+  // 72 KiB of dynamic LDS for the 128x128 tiles: above the 64 KiB default cap.  The attribute is per device (a process may
+  // drive several): set once for every device a launch is seen on.
+  {
+    static bool attr_done[64] = {};
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_f32_kernel<128, 128, 2, 2>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * LDK * (int)sizeof(float));
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_f32_v2_kernel<128, 128, 2, 2, 32>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 36 * (int)sizeof(float));
+      attr_done[dev] = true;
+    }
   }
-  const bool force_v1 = getenv("DF_IGEMM_V1") != nullptr;   // dev switch: A/B against the un-pipelined kernel
-  const size_t in_bytes = ((size_t)p.B * p.H * p.W * p.in_ld + (size_t)(p.zcount - 1) * p.z_in_coff) * sizeof(float);
+  static const bool force_v1 = getenv("DF_IGEMM_V1") != nullptr;   // dev switch: A/B against the un-pipelined kernel; read once
+  const size_t in_bytes = (size_t)p.B * p.H * p.W * p.in_ld * sizeof(float);      // per z slice
   const size_t w_bytes = (size_t)p.Cout * p.KH * p.KW * p.Cin * sizeof(float);
   const bool v2 = !force_v1 && p.up == 1 && in_bytes < (1ull << 32) && w_bytes < (1ull << 32) && p.Cout % 4 == 0 && p.out_ld % 4 == 0 &&
                   p.out_coff % 4 == 0 && p.z_out_coff % 4 == 0 && (!p.res || (p.res_ld % 4 == 0 && p.res_coff % 4 == 0)) &&
                   (!p.bias || (p.bias_group_ld % 4 == 0 && p.z_bias % 4 == 0));
   if (v2) {
-    static bool attr2 = false;
-    if (!attr2) {
-      hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_f32_v2_kernel<128, 128, 2, 2, 32>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 36 * (int)sizeof(float));
-      attr2 = true;
-    }
     if (c.bm == 128 && c.bn == 128)
       hipLaunchKernelGGL((igemm_f32_v2_kernel<128, 128, 2, 2, 32>), grid, dim3(256), (size_t)2 * 256 * 36 * sizeof(float), st, pl);
     else      // (a BK = 64 form of the small tile was measured: 0.85-1.0x, dropped)

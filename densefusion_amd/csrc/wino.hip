@@ -62,7 +62,7 @@ __global__ __launch_bounds__(WB) void wino_weight_kernel(const float *__restrict
 
 // V[z][t][c] = (B^T d B)[i][j],  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]];  one thread per (tile, 4 channels)
 __global__ __launch_bounds__(WB) void wino_input_kernel(const float *__restrict__ x, int in_ld, int in_coff, float *__restrict__ V, int H,
-                                                        int W, int C, int d, int TH, int TW, long T) {
+                                                        int W, int C, int d, int TH, int TW, long T, long Ttot, long t0) {
   const int c4n = C >> 2;
   const long total = T * c4n;
   for (long e = (long)blockIdx.x * WB + threadIdx.x; e < total; e += (long)gridDim.x * WB) {
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(WB) void wino_input_kernel(const float *__restrict_
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float4 *dst = reinterpret_cast<float4 *>(V + ((size_t)(i * 4) * T + t) * C + c);
-      const size_t zs = (size_t)T * C / 4;          // float4 stride between z planes
+      float4 *dst = reinterpret_cast<float4 *>(V + ((size_t)(i * 4) * Ttot + t0 + t) * C + c);
+      const size_t zs = (size_t)Ttot * C / 4;       // float4 stride between z planes
       dst[0] = f4sub(r[i][0], r[i][2]);
       dst[zs] = f4add(r[i][1], r[i][2]);
       dst[2 * zs] = f4sub(r[i][2], r[i][1]);
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(WB) void wino_input_kernel(const float *__restrict_
 __global__ __launch_bounds__(WB) void wino_output_kernel(const float *__restrict__ Mz, float *__restrict__ out, int out_ld, int out_coff,
                                                          const float *__restrict__ bias, const float *__restrict__ res, int res_ld,
                                                          int res_coff, int act, int H, int W,
-                                                         int C, int d, int TH, int TW, long T) {
+                                                         int C, int d, int TH, int TW, long T, long Ttot, long t0) {
   const int c4n = C >> 2;
   const long total = T * c4n;
   for (long e = (long)blockIdx.x * WB + threadIdx.x; e < total; e += (long)gridDim.x * WB) {
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(WB) void wino_output_kernel(const float *__restrict
     const TileId id = tile_of((int)t, d, TH, TW);
     const int oy = id.ry + d * 2 * id.ty, ox = id.rx + d * 2 * id.tx;
     if (oy >= H || ox >= W) continue;                // padding tile of a short sub-lattice
-    const size_t zs = (size_t)T * C / 4;
-    const float4 *src = reinterpret_cast<const float4 *>(Mz + (size_t)t * C + c);
+    const size_t zs = (size_t)Ttot * C / 4;
+    const float4 *src = reinterpret_cast<const float4 *>(Mz + (size_t)(t0 + t) * C + c);
     float4 s0[4], s1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -176,16 +176,20 @@ void launch_wino_weight(const float *w_packed, float *U, int O, int C, hipStream
   hipLaunchKernelGGL(wino_weight_kernel, dim3(blocks_for((long)O * C)), dim3(WB), 0, st, w_packed, U, O, C);
 }
 
-void launch_wino_input(const float *x, int in_ld, int in_coff, float *V, int B, int H, int W, int C, int dil, hipStream_t st) {
+void launch_wino_input(const float *x, int in_ld, int in_coff, float *V, int B, int H, int W, int C, int dil, hipStream_t st, long Ttot,
+                       long t0) {
   const WinoGeom g = wino_geom(B, H, W, dil);
-  hipLaunchKernelGGL(wino_input_kernel, dim3(blocks_for(g.T * (C / 4))), dim3(WB), 0, st, x, in_ld, in_coff, V, H, W, C, dil, g.TH, g.TW, g.T);
+  if (Ttot <= 0) { Ttot = g.T; t0 = 0; }
+  hipLaunchKernelGGL(wino_input_kernel, dim3(blocks_for(g.T * (C / 4))), dim3(WB), 0, st, x, in_ld, in_coff, V, H, W, C, dil, g.TH, g.TW, g.T,
+                     Ttot, t0);
 }
 
 void launch_wino_output(const float *M, float *out, int out_ld, int out_coff, const float *bias, const float *res, int res_ld, int res_coff,
-                        int act, int B, int H, int W, int C, int dil, hipStream_t st) {
+                        int act, int B, int H, int W, int C, int dil, hipStream_t st, long Ttot, long t0) {
   const WinoGeom g = wino_geom(B, H, W, dil);
+  if (Ttot <= 0) { Ttot = g.T; t0 = 0; }
   hipLaunchKernelGGL(wino_output_kernel, dim3(blocks_for(g.T * (C / 4))), dim3(WB), 0, st, M, out, out_ld, out_coff, bias, res, res_ld,
-                     res_coff, act, H, W, C, dil, g.TH, g.TW, g.T);
+                     res_coff, act, H, W, C, dil, g.TH, g.TW, g.T, Ttot, t0);
 }
 
 }  // namespace df

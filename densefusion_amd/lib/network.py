@@ -222,3 +222,43 @@ class PoseEstimator:
                                      self._ws.numel(), _lib.current_stream())
         _lib.check(st, "estimate_poses")
         return pose_wo, pose
+
+    def estimate_multi(self, imgs, cloud, choose, obj, iteration, out=None):
+        """A window of detections of different crop sizes in one device-side call (``df_estimate_poses_multi``).
+
+        ``imgs``: list of ``[B_i,3,H_i,W_i]`` tensors, one per crop-size bucket; ``cloud [sum B,N,3]``, ``choose [sum B,N]``,
+        ``obj [sum B]``: the objects of all buckets concatenated in bucket order.  Returns ``(pose_wo_refine, pose)``, each
+        ``[sum B,7]`` f64 in the same order; bit-identical to per-bucket ``estimate`` calls."""
+        import ctypes
+        self.estimator._check_mode(); self.refiner._check_mode()
+        imgs = [_dev_f32(i) for i in imgs]
+        cloud = _dev_f32(cloud)
+        dev = cloud.device
+        N = self.estimator.num_points
+        nb = len(imgs)
+        Bs = [int(i.shape[0]) for i in imgs]
+        Btot = sum(Bs)
+        if nb == 0 or any(i.dim() != 4 or i.shape[1] != 3 for i in imgs) or cloud.shape != (Btot, N, 3):
+            raise RuntimeError(f"estimate_multi: need images [B_i,3,H_i,W_i] and cloud [{Btot},{N},3], got "
+                               f"{[tuple(i.shape) for i in imgs]}, {tuple(cloud.shape)}")
+        choose = choose.to(device=dev, dtype=torch.int64).reshape(Btot, N).contiguous()
+        obj = obj.to(device=dev, dtype=torch.int64).reshape(Btot).contiguous()
+        if out is None:
+            out = (torch.empty(Btot, 7, dtype=torch.float64, device=dev), torch.empty(Btot, 7, dtype=torch.float64, device=dev))
+        pose_wo, pose = out
+        arr = ctypes.c_int * nb
+        cB, cH, cW = arr(*Bs), arr(*[int(i.shape[2]) for i in imgs]), arr(*[int(i.shape[3]) for i in imgs])
+        cimg = (ctypes.c_void_p * nb)(*[i.data_ptr() for i in imgs])
+        L = _lib.lib()
+        with _lib.device_guard(dev):
+            hp, hr = self.estimator._engine(dev), self.refiner._engine(dev)
+            need = L.df_estimate_multi_workspace_bytes(hp, hr, nb, cB, cH, cW)
+            if need == 0:
+                _lib.check(-1, "estimate_multi_workspace_bytes")
+            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+                self._ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+            st = L.df_estimate_poses_multi(hp, hr, nb, cB, cH, cW, cimg, cloud.data_ptr(), choose.data_ptr(), obj.data_ptr(),
+                                           int(iteration), pose_wo.data_ptr(), pose.data_ptr(), self._ws.data_ptr(),
+                                           self._ws.numel(), _lib.current_stream())
+        _lib.check(st, "estimate_poses_multi")
+        return pose_wo, pose

@@ -98,6 +98,19 @@ int df_estimate_poses(df_net *posenet, df_net *refiner, int B, int H, int W, con
                       const int64_t *choose, const int64_t *obj, int iters, double *pose_wo, double *pose, void *ws,
                       size_t ws_bytes, df_stream_t stream);
 
+/* The same for a window of detections of DIFFERENT crop sizes (the objects tools/eval_ycb.py:147-237 meets over a run of frames,
+ * bucketed by their snapped box size, eval_ycb.py:54-90): nb buckets, bucket i = B[i] objects of H[i] x W[i] with images
+ * img[i] = [B[i]][3][H[i]][W[i]] (host arrays of nb entries; the pointers are device pointers).  cloud / choose / obj / pose_wo /
+ * pose hold the objects of all buckets concatenated in bucket order ([sum B][N][3], [sum B][N], [sum B], [sum B][7]).
+ * Everything that does not depend on the crop geometry (1x1 convolutions, Winograd-domain products, low-resolution up-conv
+ * products, the whole per-point part and every refine iteration) is ONE launch over all buckets; results are bit-identical to
+ * per-bucket df_estimate_poses calls. */
+size_t df_estimate_multi_workspace_bytes(const df_net *posenet, const df_net *refiner, int nb, const int *B, const int *H,
+                                         const int *W);
+int df_estimate_poses_multi(df_net *posenet, df_net *refiner, int nb, const int *B, const int *H, const int *W,
+                            const float *const *img, const float *cloud, const int64_t *choose, const int64_t *obj, int iters,
+                            double *pose_wo, double *pose, void *ws, size_t ws_bytes, df_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * ADD / ADD-S loss and metric, forward (replace lib/loss.py:13-70, lib/loss_refiner.py:12-62 and the
  * metric of tools/eval_linemod.py:118-130).  One object per call, like the reference (bs = 1).
@@ -218,10 +231,13 @@ int df_conv2d_wgrad_nhwc(const df_conv_desc *d, const float *dy, float *dw, floa
 
 /* Per-launch timing of the GEMM kernel with HIP events on the call's stream (bench.py roofline).
  * df_net_profile(net, 1) arms it; after the stream has been synchronised df_net_profile_read returns the
- * summed duration (ms), the algorithmic FLOPs, the algorithmic HBM bytes (each input, weight, output element once) and
- * the number of GEMM launches since arming, and re-arms. */
+ * summed duration (ms), the FLOPs the launches perform (2 M N K per launch, M = the rows launched), the part of them spent on
+ * rows that are not padding (`gemm_useful_flops`: points beyond num_points in a 128-padded object block and Winograd tiles
+ * beyond the map edge excluded), the algorithmic HBM bytes (each input, weight, output element once) and the number of GEMM
+ * launches since arming, and re-arms. */
 int df_net_profile(df_net *net, int enable);
-int df_net_profile_read(df_net *net, double *gemm_ms, double *gemm_flops, double *gemm_bytes, int *launches);
+int df_net_profile_read(df_net *net, double *gemm_ms, double *gemm_flops, double *gemm_useful_flops, double *gemm_bytes,
+                        int *launches);
 
 #ifdef __cplusplus
 }

@@ -251,3 +251,35 @@ def test_large_crops_vs_oracle(H, W, B):
         _close(emb[i], o_e[0]); _close(r[i], o_r[0]); _close(t[i], o_t[0]); _close(c[i], o_c[0])
         if float(cs[-1] - cs[-2]) > 1e-4:
             assert _add(pose[i].cpu().numpy(), opose, b["model_points"][i]) < ADD_TOL
+
+
+def test_multi_bucket_call_equals_per_bucket_calls():
+    """df_estimate_poses_multi: a window of detections of different crop sizes in one call (shared launches for everything
+    that does not depend on the crop geometry) == one df_estimate_poses call per crop size, bit for bit; includes a crop whose
+    dilated layers skip the Winograd route, a non-multiple-of-8 crop and a one-object bucket."""
+    from densefusion_amd.lib.network import PoseEstimator
+    K, N = 21, 1000
+    est, ref = _nets(K, N, 13)
+    pe = PoseEstimator(est, ref)
+    shapes = [(3, 80, 80), (2, 120, 160), (1, 92, 108), (2, 160, 160)]
+    bs = [synth.make_batch(500 + i, B, H, W, N, K) for i, (B, H, W) in enumerate(shapes)]
+    T = lambda b, k: torch.from_numpy(b[k]).cuda()
+    cat = lambda k: torch.cat([T(b, k) for b in bs])
+    for iters in (2, 0):
+        wo, pose = pe.estimate_multi([T(b, "img") for b in bs], cat("cloud"), cat("choose").reshape(-1, N), cat("obj").reshape(-1), iters)
+        assert wo.shape == (8, 7) and pose.shape == (8, 7)
+        o = 0
+        for b, (B, H, W) in zip(bs, shapes):
+            wo1, pose1 = PoseEstimator(est, ref).estimate(T(b, "img"), T(b, "cloud"), T(b, "choose"), T(b, "obj"), iters)
+            assert torch.equal(wo1, wo[o:o + B]) and torch.equal(pose1, pose[o:o + B]), (H, W, iters)
+            o += B
+    # and the oracle agrees on one object of the odd-sized bucket
+    sdp = dfnet._to_torch_sd(synth.make_state_dict(synth.posenet_spec(K), 13))
+    sdr = dfnet._to_torch_sd(synth.make_state_dict(synth.refiner_spec(K), 1013))
+    with torch.no_grad():
+        args = tuple(torch.from_numpy(bs[2][k][0:1]) for k in ("img", "cloud", "choose", "obj"))
+        _, opose = pose_math.estimate_pose(sdp, sdr, *args, 2)
+    _, pose = pe.estimate_multi([T(b, "img") for b in bs], cat("cloud"), cat("choose").reshape(-1, N), cat("obj").reshape(-1), 2)
+    assert _add(pose[5].cpu().numpy(), opose, bs[2]["model_points"][0]) < ADD_TOL
+    with pytest.raises(RuntimeError):
+        pe.estimate_multi([T(bs[0], "img")], cat("cloud"), cat("choose"), cat("obj"), 2)      # object counts disagree
