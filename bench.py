@@ -235,6 +235,40 @@ def bench_knn():
             "bound": "fp32-valu (arithmetic intensity 9R/20 = 225 FLOP/B >> ridge ~20)"}
 
 
+def bench_loss():
+    """The symmetric PoseNet loss forward at BASELINE configs[3]'s size (N = 1000 per-point poses x M = 500 mesh points =
+    250 M pairs; lib/loss.py:38-50 with the 1-NN of lib/knn): transform + 1-NN + distance reduction in one launch
+    (csrc/loss.hip add_dis_sym_kernel, the scan of csrc/knn_core.h) + the small finishing kernel."""
+    N, M = 1000, 500
+    dev = "cuda"
+    g = torch.Generator(device="cpu").manual_seed(7)
+    q = torch.randn(N, 4, generator=g).to(dev); pt = (torch.randn(N, 3, generator=g) * 0.03).to(dev)
+    pc = (torch.rand(N, generator=g) * 0.9 + 0.05).to(dev)
+    mp = ((torch.rand(M, 3, generator=g) - 0.5) * 0.2).to(dev); tgt = mp + 0.5; pts = (torch.rand(N, 3, generator=g) * 0.1 + 0.45).to(dev)
+    loss, dis = torch.empty(1, device=dev), torch.empty(1, device=dev)
+    npts, ntgt, scratch = torch.empty(N, 3, device=dev), torch.empty(M, 3, device=dev), torch.empty(N, device=dev)
+    sel = torch.empty(N, M, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+
+    def call():
+        _lib.check(L.df_loss_forward(q.data_ptr(), pt.data_ptr(), pc.data_ptr(), tgt.data_ptr(), mp.data_ptr(), pts.data_ptr(), N, M,
+                                     ctypes.c_float(0.015), 1, loss.data_ptr(), dis.data_ptr(), npts.data_ptr(), ntgt.data_ptr(),
+                                     scratch.data_ptr(), sel.data_ptr(), _lib.current_stream()), "loss_forward")
+    for _ in range(3):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    n = 50
+    e0.record()
+    for _ in range(n):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    return {"N": N, "M": M, "pairs": N * M * M, "us_per_forward": round(us, 2), "achieved_TFLOPs": round(9.0 * N * M * M / us / 1e6, 2),
+            "fp32_valu_frac": round(9.0 * N * M * M / us / 1e6 / FP32_PEAK_TFLOPS, 4)}
+
+
 def host_threads():
     """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota (a GPU box
     exposes all host cores in os.cpu_count() but grants a 16-core share per GPU)."""
@@ -441,6 +475,7 @@ def main():
                            "gemm_ms_per_step": round(ms / max(1, min(args.steps, 5)), 3)}
         if not args.no_knn:
             out["knn"] = bench_knn()
+            out["knn"]["symmetric_loss_forward"] = bench_loss()
             out["latency_single_object"] = bench_latency(est, ref, device)
         if world == 1 and not args.no_cpu_baseline:
             gpu_poses = bucket_poses(buckets, groups)

@@ -44,6 +44,10 @@ struct Net {
   std::vector<double> ev_flops, ev_bytes, ev_useful;
   std::vector<std::string> ev_desc;
   size_t ev_used = 0;
+  // debug taps (df_net_debug_taps): copies of named intermediates of the last single-bucket forward, channels-last
+  bool taps_on = false;
+  struct Tap { float *buf = nullptr; size_t cap = 0; int64_t shape[4] = {0, 0, 0, 0}; };
+  std::map<std::string, Tap> taps;
 };
 
 static void add(Net &n, const std::string &key, std::initializer_list<int64_t> shp) {
@@ -321,6 +325,20 @@ struct Ctx {
   }
   // `useful`: the fraction of the launch's rows that are not padding (points beyond N in a 128-padded object block, Winograd
   // tiles beyond the map edge) -- only for the profile's useful-FLOP tally
+  // debug tap: keep a copy of an intermediate (allocates: debug mode only, never under graph capture)
+  void tap(const char *name, const float *src, int64_t d0, int64_t d1, int64_t d2, int64_t d3) {
+    if (!live() || !net->taps_on || !src) return;
+    Net::Tap &t = net->taps[name];
+    const size_t n = (size_t)d0 * d1 * d2 * d3;
+    if (t.cap < n) {
+      if (t.buf) hipFree(t.buf);
+      t.buf = nullptr; t.cap = 0;
+      if (hipMalloc(&t.buf, n * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return; }
+      t.cap = n;
+    }
+    t.shape[0] = d0; t.shape[1] = d1; t.shape[2] = d2; t.shape[3] = d3;
+    hipMemcpyAsync(t.buf, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+  }
   double pt_useful = 1.0;      // N / Npad of the per-point launches
   void pconv(const ConvParams &p) { conv(p, pt_useful); }
   void conv(const ConvParams &p, double useful = 1.0) {
@@ -439,6 +457,7 @@ static float *cnn_forward(Ctx &c, const std::vector<Grp> &gs, Level &half_lv) {
       float *stem = c.f((size_t)g.B * l0.h[i] * l0.w[i] * 64);
       c.conv(conv2d(img4, g.B, g.H, g.W, 4, 4, c.w(P + "feats.conv1.weight"), nullptr, stem, l0.h[i], l0.w[i], 64, 64, 0, 7, 2, 3, 1, ACT_RELU));
       if (c.live()) launch_maxpool3s2(stem, x + l1.off[i] * 64, g.B, l0.h[i], l0.w[i], 64, l1.h[i], l1.w[i], c.st);
+      if (nb == 1) c.tap("stem", stem, g.B, l0.h[i], l0.w[i], 64);
     }
     c.off = mark;
     (void)mark;
@@ -511,6 +530,7 @@ static float *cnn_forward(Ctx &c, const std::vector<Grp> &gs, Level &half_lv) {
     float *o1 = c.f((size_t)lo.rows * planes);
     conv3x3(t1, lo, planes, base + "1.conv2.weight", o1, lo, planes, 1, d, o0);
     x = o1; lx = lo; cin = planes;
+    if (nb == 1) c.tap(("layer" + std::to_string(li)).c_str(), x, gs[0].B, lx.h[0], lx.w[0], planes);
   }
   // PSP module (lib/pspnet.py:20-24) with the bottleneck folded through the pyramid:
   //   bottleneck(cat(up(W_s pool_s(f)), f)) = W_b[:,2048:] f + sum_s up((W_b[:,512s:512s+512] W_s) pool_s(f)) + b
@@ -533,6 +553,7 @@ static float *cnn_forward(Ctx &c, const std::vector<Grp> &gs, Level &half_lv) {
     p.res = prior; p.res_ld = 1024;
     c.conv(p);
   }
+  if (nb == 1) c.tap("psp", psp, gs[0].B, lx.h[0], lx.w[0], 1024);
   // PSPUpsample stages up_1, up_2 (lib/pspnet.py:27-37,69-73; dropout = identity in eval), each as a low-resolution
   // GEMM with N = 9*Cout (one launch for all buckets) followed by the per-bucket 9-tap interpolation (layers.hip).  up_3 is NOT run
   // here: its output is read at the chosen pixels only, so the caller evaluates it there from the maps returned: [B][h][w][64].
@@ -556,6 +577,7 @@ static float *cnn_forward(Ctx &c, const std::vector<Grp> &gs, Level &half_lv) {
     (void)mark;
     lx = lo;
     cur = o;
+    if (nb == 1) c.tap(ups[u], cur, gs[0].B, lx.h[0], lx.w[0], up_out[u]);
   }
   half_lv = lx;
   return cur;
@@ -587,6 +609,7 @@ static void posenet_points(Ctx &c, int B, int N, int Npad, const float *cloud, c
   c.pconv(p6);
   float *apx = c.f((size_t)B * 1024);
   if (c.live()) launch_colsum_finish(partial, prow / B, apx, B, 1024, N, c.st);
+  c.tap("ap_x", apx, B, 1024, 1, 1);
   // head layer 1: W[:, :384] . pointfeat + (W[:, 384:] . ap_x + b) -- the 1024 broadcast channels of the
   // 1408-wide input are identical for every point of an object, so they collapse into a per-object bias
   float *gbias = c.f((size_t)B * 1920);
@@ -655,6 +678,7 @@ static void posenet_forward(Ctx &c, const std::vector<Grp> &gs, const float *clo
     p.prelu = c.w(P + "up_3.conv.2.weight");
     c.pconv(p);
   }
+  if (gs.size() == 1) c.tap("up_3", z3, B, Npad, 64, 1);      // rows of the chosen pixels only
   o.emb_pm = c.f((size_t)B * Npad * 32);
   if (c.live()) launch_final_logsoftmax(z3, c.w(P + "final.0.weight"), c.w(P + "final.0.bias"), o.emb, o.emb_pm, B, N, Npad, c.st);
   posenet_points(c, B, N, Npad, cloud, o.emb_pm, obj, o.out_r, o.out_t, o.out_c, sel);
@@ -753,6 +777,7 @@ extern "C" void df_net_destroy(df_net *h) {
   if (!h) return;
   Net *n = as_net(h);
   for (auto &kv : n->buf) hipFree(kv.second);
+  for (auto &kv : n->taps) if (kv.second.buf) hipFree(kv.second.buf);
   for (auto e : n->ev) hipEventDestroy(e);
   delete n;
 }
@@ -814,6 +839,31 @@ extern "C" int df_net_profile_read(df_net *h, double *gemm_ms, double *gemm_flop
   n->ev_bytes.clear();
   n->ev_useful.clear();
   n->ev_desc.clear();
+  return DF_OK;
+}
+
+extern "C" int df_net_debug_taps(df_net *h, int enable) {
+  if (!h) return set_error(DF_ERR_ARG, "debug_taps: null handle");
+  Net *n = as_net(h);
+  n->taps_on = enable != 0;
+  if (!enable) {
+    for (auto &kv : n->taps) if (kv.second.buf) hipFree(kv.second.buf);
+    n->taps.clear();
+  }
+  return DF_OK;
+}
+
+extern "C" int df_net_debug_tap_read(df_net *h, const char *name, float *dst, int64_t cap, int64_t *shape4) {
+  if (!h || !name) return set_error(DF_ERR_ARG, "debug_tap_read: null handle / name");
+  Net *n = as_net(h);
+  auto it = n->taps.find(name);
+  if (it == n->taps.end() || !it->second.buf) return set_error(DF_ERR_STATE, "debug_tap_read: no tap named '%s' (arm df_net_debug_taps and run a single-bucket forward)", name);
+  const Net::Tap &t = it->second;
+  const int64_t numel = t.shape[0] * t.shape[1] * t.shape[2] * t.shape[3];
+  if (shape4) for (int i = 0; i < 4; ++i) shape4[i] = t.shape[i];
+  if (!dst) return DF_OK;          // shape query
+  if (cap < numel) return set_error(DF_ERR_ARG, "debug_tap_read: destination holds %lld floats, tap '%s' has %lld", (long long)cap, name, (long long)numel);
+  if (hipMemcpy(dst, t.buf, (size_t)numel * sizeof(float), hipMemcpyDefault) != hipSuccess) return set_error(DF_ERR_LAUNCH, "debug_tap_read: copy failed");
   return DF_OK;
 }
 

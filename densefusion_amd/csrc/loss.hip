@@ -9,6 +9,7 @@
 // tensor ever reaches HBM.  The nearest-neighbour choice uses the same arithmetic as csrc/knn.hip
 // (fma chain in coordinate order, strict '<', lowest index wins).
 #include "common.h"
+#include "knn_core.h"
 
 namespace df {
 namespace {
@@ -92,6 +93,70 @@ __global__ __launch_bounds__(LB) void add_dis_kernel(const float *__restrict__ p
   }
   const float tot = block_sum(acc, s_red);
   if (tid == 0) dis[p] = tot / (float)M;
+}
+
+// Symmetric objects, many poses (the PoseNet loss: N per-point poses, lib/loss.py:41-47): the N*M transformed model points
+// are the queries of a 1-NN against the M target points.  Same scan as df_knn (knn_core.h: packed v_pk_*_f32 pairs, four
+// queries per lane, chunked arg-min, targets as wave-uniform LDS broadcasts), so `sel` is bit for bit what
+// KNearestNeighbor(1)(target, pred) would return; a workgroup owns `ppb` whole poses (their ppb*M queries in passes of
+// 256*QPL) so that the per-pose distance sums stay inside the workgroup and deterministic.
+constexpr int SYM_QPL = 4;
+__global__ __launch_bounds__(LB) void add_dis_sym_kernel(const float *__restrict__ pred_r, const float *__restrict__ pred_t,
+                                                         const float *__restrict__ points, const float *__restrict__ target,
+                                                         const float *__restrict__ model, int P, int M, int ppb,
+                                                         float *__restrict__ dis, int *__restrict__ sel_out) {
+  extern __shared__ __attribute__((aligned(16))) float s_tgt[];   // [M][4], then LB*SYM_QPL distances, then ppb totals
+  __shared__ float s_red[LB];
+  float *s_e = s_tgt + (size_t)M * 4;
+  float *s_tot = s_e + LB * SYM_QPL;
+  const int tid = threadIdx.x;
+  const int p0 = blockIdx.x * ppb, np = min(ppb, P - p0);
+  for (int m = tid; m < M; m += LB)
+    reinterpret_cast<float4 *>(s_tgt)[m] = make_float4(target[m * 3], target[m * 3 + 1], target[m * 3 + 2], 0.f);
+  if (tid < ppb) s_tot[tid] = 0.f;
+  __syncthreads();
+  const int total = np * M;
+  for (int base = 0; base < total; base += LB * SYM_QPL) {
+    float qx[SYM_QPL], qy[SYM_QPL], qz[SYM_QPL];
+    int bi[SYM_QPL], pi[SYM_QPL], mi[SYM_QPL];
+#pragma unroll
+    for (int j = 0; j < SYM_QPL; ++j) {
+      const int i = base + tid + j * LB;
+      const int ic = i < total ? i : total - 1;        // clamp: idle lanes work on a valid point and store nothing
+      const int slot = ic / M, m = ic - slot * M, p = p0 + slot;
+      pi[j] = p; mi[j] = m;
+      const Rot R = quat_rot(pred_r + p * 4);
+      float t0 = pred_t[p * 3], t1 = pred_t[p * 3 + 1], t2 = pred_t[p * 3 + 2];
+      if (points) { t0 = points[p * 3] + t0; t1 = points[p * 3 + 1] + t1; t2 = points[p * 3 + 2] + t2; }
+      const float x = model[m * 3], y = model[m * 3 + 1], z = model[m * 3 + 2];
+      // bmm(model_points, base) with base = R^T (lib/loss.py:29,38), then + (points + pred_t): the same expression as add_dis_kernel
+      qx[j] = (x * R.m[0] + y * R.m[1] + z * R.m[2]) + t0;
+      qy[j] = (x * R.m[3] + y * R.m[4] + z * R.m[5]) + t1;
+      qz[j] = (x * R.m[6] + y * R.m[7] + z * R.m[8]) + t2;
+    }
+    knn1_scan<SYM_QPL>(s_tgt, M, qx, qy, qz, bi);
+#pragma unroll
+    for (int j = 0; j < SYM_QPL; ++j) {
+      const int i = base + tid + j * LB;
+      const bool ok = i < total;
+      const float4 q = reinterpret_cast<const float4 *>(s_tgt)[bi[j]];
+      const float ex = qx[j] - q.x, ey = qy[j] - q.y, ez = qz[j] - q.z;
+      s_e[tid + j * LB] = ok ? sqrtf(ex * ex + ey * ey + ez * ez) : 0.f;
+      if (ok && sel_out) sel_out[(size_t)pi[j] * M + mi[j]] = bi[j];      // kept for the backward pass
+    }
+    __syncthreads();
+    // per-pose sums of this pass, in a fixed order
+    const int s_lo = base / M, s_hi = (min(base + LB * SYM_QPL, total) - 1) / M;
+    for (int sl = s_lo; sl <= s_hi; ++sl) {
+      const int lo = max(sl * M, base) - base, hi = min(min((sl + 1) * M, base + LB * SYM_QPL), total) - base;
+      float v = 0.f;
+      for (int k = lo + tid; k < hi; k += LB) v += s_e[k];
+      const float tot = block_sum(v, s_red);
+      if (tid == 0) s_tot[sl] += tot;
+    }
+    __syncthreads();
+  }
+  if (tid < np) dis[p0 + tid] = s_tot[tid] / (float)M;
 }
 
 // Backward of dis_p = mean_m || R(q_p/|q_p|) x_m + t_p - tgt_sel(p,m) ||  w.r.t. q_p (un-normalised) and t_p,
@@ -336,9 +401,24 @@ __global__ __launch_bounds__(LB) void ycb_dist_kernel(const double *__restrict__
   if (tid == 0) { add_out[b] = s_red[0][0] / (double)M; adi_out[b] = s_red[1][0] / (double)M; }
 }
 
+// 150 KB of dynamic LDS for the kernels that keep a whole point set resident: a per-DEVICE attribute (a process may drive
+// several devices), set the first time a launch is seen on a device
+void loss_lds_attrs();
+
 int check_m(int M, const char *what) {
   if (M <= 0 || (size_t)M * 16 > 150 * 1024) return set_error(DF_ERR_ARG, "%s: num_points_mesh must be in [1, 9600] (got %d)", what, M);
   return DF_OK;
+}
+
+void loss_lds_attrs() {
+  static bool done[64] = {};
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || done[dev]) return;
+  const void *ks[] = {reinterpret_cast<const void *>(&add_dis_kernel), reinterpret_cast<const void *>(&add_dis_sym_kernel),
+                      reinterpret_cast<const void *>(&add_metric_kernel), reinterpret_cast<const void *>(&ycb_dist_kernel)};
+  for (const void *k : ks) hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  done[dev] = true;
 }
 
 }  // namespace
@@ -358,13 +438,17 @@ extern "C" int df_loss_forward(const float *pred_r, const float *pred_t, const f
   if (rc != DF_OK) return rc;
   hipStream_t st = to_stream(stream);
   const size_t lds = (size_t)M * 16;
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&add_dis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&add_metric_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr = true;
+  loss_lds_attrs();
+  const int ppb = M >= LB * SYM_QPL ? 1 : (LB * SYM_QPL) / M;
+  const size_t lds2 = (size_t)M * 16 + (size_t)LB * SYM_QPL * 4 + (size_t)ppb * 4;
+  if (symmetric && N >= 2 && lds2 <= 150 * 1024) {
+    // the fused transform + shared 1-NN scan (knn_core.h) + distance reduction; ppb whole poses per workgroup fill its
+    // 256 lanes x 4 queries
+    hipLaunchKernelGGL(add_dis_sym_kernel, dim3((N + ppb - 1) / ppb), dim3(LB), lds2, st, pred_r, pred_t, points, target, model_points, N, M, ppb,
+                       dis_scratch, sel_out);
+  } else {
+    hipLaunchKernelGGL(add_dis_kernel, dim3(N), dim3(LB), lds, st, pred_r, pred_t, points, target, model_points, M, symmetric, dis_scratch, sel_out);
   }
-  hipLaunchKernelGGL(add_dis_kernel, dim3(N), dim3(LB), lds, st, pred_r, pred_t, points, target, model_points, M, symmetric, dis_scratch, sel_out);
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(LB), 0, st, pred_r, pred_t, pred_c, points, target, dis_scratch, N, M, w,
                      loss_out, dis_out, new_points, new_target);
   return check_launch("loss_forward");
@@ -379,11 +463,7 @@ extern "C" int df_loss_refine_forward(const float *pred_r, const float *pred_t, 
   int rc = check_m(M, "loss_refine_forward");
   if (rc != DF_OK) return rc;
   hipStream_t st = to_stream(stream);
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&add_dis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr = true;
-  }
+  loss_lds_attrs();
   hipLaunchKernelGGL(add_dis_kernel, dim3(1), dim3(LB), (size_t)M * 16, st, pred_r, pred_t, (const float *)nullptr, target,
                      model_points, M, symmetric, dis_out, sel_out);
   hipLaunchKernelGGL(recentre_kernel, dim3(cdiv(N + M, LB)), dim3(LB), 0, st, pred_r, pred_t, points, target, N, M, new_points, new_target);
@@ -396,11 +476,7 @@ extern "C" int df_add_metric(const double *pose, const float *model_points, cons
   if (B <= 0) return set_error(DF_ERR_ARG, "add_metric: B must be >= 1");
   int rc = check_m(M, "add_metric");
   if (rc != DF_OK) return rc;
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&add_metric_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr = true;
-  }
+  loss_lds_attrs();
   hipLaunchKernelGGL(add_metric_kernel, dim3(B), dim3(LB), (size_t)M * 16, to_stream(stream), pose, model_points, target, symmetric, M, dis_out);
   return check_launch("add_metric");
 }
@@ -409,11 +485,7 @@ extern "C" int df_ycb_distances(const double *rt_est, const double *rt_gt, const
                                 double *adi_out, df_stream_t stream) {
   if (!rt_est || !rt_gt || !pts || !add_out || !adi_out) return set_error(DF_ERR_ARG, "ycb_distances: null pointer");
   if (B <= 0 || M <= 0 || (size_t)M * 24 > 150 * 1024) return set_error(DF_ERR_ARG, "ycb_distances: need B >= 1 and 1 <= M <= 6400");
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&ycb_dist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr = true;
-  }
+  loss_lds_attrs();
   hipLaunchKernelGGL(ycb_dist_kernel, dim3(B), dim3(LB), (size_t)M * 24, to_stream(stream), rt_est, rt_gt, pts, M, add_out, adi_out);
   return check_launch("ycb_distances");
 }

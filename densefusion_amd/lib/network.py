@@ -101,6 +101,24 @@ class _EngineModule(nn.Module):
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         return self._ws
 
+    def debug_taps(self, enable=True):
+        """Arm / disarm the engine's debug taps (``df_net_debug_taps``): the next single-bucket forward keeps copies of its
+        named intermediates, read back with ``debug_tap``."""
+        dev = next(self.parameters()).device
+        with _lib.device_guard(dev):
+            _lib.check(_lib.lib().df_net_debug_taps(self._engine(dev), 1 if enable else 0), "debug_taps")
+
+    def debug_tap(self, name):
+        """One intermediate of the last forward as a host tensor in the engine's channels-last layout (see include/dfusion.h)."""
+        import ctypes
+        torch.cuda.synchronize()
+        L = _lib.lib()
+        shape = (ctypes.c_int64 * 4)()
+        _lib.check(L.df_net_debug_tap_read(self._handle, name.encode(), None, 0, shape), f"debug_tap_read({name})")
+        out = torch.empty([int(v) for v in shape], dtype=torch.float32)
+        _lib.check(L.df_net_debug_tap_read(self._handle, name.encode(), out.data_ptr(), out.numel(), shape), f"debug_tap_read({name})")
+        return out
+
     def _check_mode(self):
         if self.training:
             raise RuntimeError(f"{type(self).__name__}: this entry point is inference-only; call .eval() first")

@@ -239,6 +239,16 @@ int df_net_profile(df_net *net, int enable);
 int df_net_profile_read(df_net *net, double *gemm_ms, double *gemm_flops, double *gemm_useful_flops, double *gemm_bytes,
                         int *launches);
 
+/* Debug taps: with df_net_debug_taps(net, 1) armed, a single-bucket PoseNet forward keeps device copies of its named
+ * intermediates (channels-last): "stem" [B][H/2][W/2][64] (conv1 + ReLU, lib/extractors.py:115-117), "layer1".."layer4",
+ * "psp" [B][H/8][W/8][1024] (lib/pspnet.py:20-24), "up_1" [B][H/4][W/4][256], "up_2" [B][H/2][W/2][64], "up_3" [B][Npad][64]
+ * (rows of the chosen pixels only, Npad = num_points rounded up to 128), "ap_x" [B][1024] (lib/network.py:65).  It allocates, so
+ * it is for debugging / layer-level parity tests only (not under hipGraph capture).  df_net_debug_tap_read copies a tap to dst
+ * (host or device, `cap` floats) after the caller has synchronised the stream and returns its shape; dst == NULL only queries
+ * the shape.  df_net_debug_taps(net, 0) frees the copies. */
+int df_net_debug_taps(df_net *net, int enable);
+int df_net_debug_tap_read(df_net *net, const char *name, float *dst, int64_t cap, int64_t *shape4);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,10 @@ CASES = [
     ("cfg2_linemod_120x160", 13, 500, 120, 160, 2, 12, 103, "linemod"),
     ("cfg3_ycb_160", 21, 1000, 160, 160, 4, 13, 104, "ycb"),
     ("cfg3_ycb_80x120", 21, 1000, 80, 120, 2, 13, 105, "ycb"),
+    # large / stress shapes (outputs only): the biggest bench crop, a full frame, and BASELINE configs[4]'s 2000 points
+    ("cfg3_ycb_240x320", 21, 1000, 240, 320, 2, 13, 106, "ycb"),
+    ("cfg3_ycb_480x640", 21, 1000, 480, 640, 2, 13, 107, "ycb"),
+    ("cfg5_n2000_240x320", 21, 2000, 240, 320, 2, 13, 108, "ycb"),
 ]
 
 
@@ -168,6 +172,45 @@ def run_loss(ref):
     print("loss", float(l), float(d), float(d2))
 
 
+def grad_sample(g, cap=8192):
+    """the whole tensor when small, else every (numel // cap)-th element of the flattened tensor"""
+    g = np.asarray(g)
+    return g if g.size <= cap else g.reshape(-1)[::g.size // cap].copy()
+
+
+def run_grad(ref):
+    """Gradient golden: the imported reference's Loss (non-symmetric idx; the symmetric branch raises in this fork)
+    .backward() through the imported PoseNet at the tiny config (tools/train.py:152-161), with the modules in eval()
+    mode so that Dropout2d (lib/pspnet.py:46,52) is the identity and the result is deterministic.  Stored: loss, dis and a
+    representative set of parameter gradients (first / middle / last layers of every part of the graph)."""
+    network, loss, _, _, _ = ref
+    K, N, H, W, M, wseed, iseed = 2, 64, 40, 40, 60, 11, 101
+    est = network.PoseNet(num_points=N, num_obj=K)
+    est.load_state_dict(t(synth.make_state_dict(synth.posenet_spec(K), wseed)), strict=True)
+    est.eval()
+    o = synth.make_object(iseed, H, W, N, K, num_points_mesh=M)
+    idx = torch.tensor([[0]])
+    T = lambda k: torch.from_numpy(o[k])[None]
+    pred_r, pred_t, pred_c, emb = est(T("img"), T("cloud"), torch.from_numpy(o["choose"]), idx)
+    crit = loss.Loss(M, [1])
+    l, d, _, _ = crit(pred_r, pred_t, pred_c, T("target"), T("model_points"), idx, T("cloud"), 0.015, False)
+    l.backward()
+    keep = ["cnn.model.module.feats.conv1.weight", "cnn.model.module.feats.layer1.0.conv1.weight",
+            "cnn.model.module.feats.layer2.0.downsample.0.weight", "cnn.model.module.feats.layer3.1.conv2.weight",
+            "cnn.model.module.feats.layer4.1.conv1.weight", "cnn.model.module.psp.stages.2.1.weight",
+            "cnn.model.module.psp.bottleneck.weight", "cnn.model.module.psp.bottleneck.bias",
+            "cnn.model.module.up_1.conv.1.weight", "cnn.model.module.up_2.conv.2.weight", "cnn.model.module.up_3.conv.1.bias",
+            "cnn.model.module.final.0.weight", "feat.conv1.weight", "feat.e_conv2.weight", "feat.conv6.bias",
+            "conv1_r.weight", "conv2_t.weight", "conv3_c.bias", "conv4_r.weight", "conv4_c.weight"]
+    grads = dict(est.named_parameters())
+    # big tensors are stored as a fixed strided sample of their flattened gradient (grad_sample below; the test takes the same)
+    out = {"grad:" + k: grad_sample(grads[k].grad.numpy()) for k in keep}
+    out.update(loss=l.detach().numpy(), dis=d.detach().numpy(), out_rx=pred_r.detach().numpy(), out_cx=pred_c.detach().numpy(),
+               meta=np.array([K, N, H, W, M, wseed, iseed, 0]))
+    np.savez_compressed(os.path.join(OUT, "grad_tiny.npz"), **out)
+    print("grad", float(l), float(d), {k[5:]: float(np.abs(v).max()) for k, v in out.items() if k.startswith("grad:")})
+
+
 def run_quat(ref):
     tf = ref[4]
     rng = np.random.Generator(np.random.PCG64(5))
@@ -234,6 +277,8 @@ def main():
             run_case(ref, *case)
     if not only or "loss" in only:
         run_loss(ref)
+    if not only or "grad" in only:
+        run_grad(ref)
     if not only or "quat" in only:
         run_quat(ref)
     if not only or "ply" in only:

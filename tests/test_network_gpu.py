@@ -47,7 +47,8 @@ def _add(p, q, mp):
     return pose_math.add_metric(pose_math.transform_model(p, mp), pose_math.transform_model(q, mp))
 
 
-@pytest.mark.parametrize("name", ["tiny", "cfg1_linemod_80", "cfg2_linemod_120x160", "cfg3_ycb_160", "cfg3_ycb_80x120"])
+@pytest.mark.parametrize("name", ["tiny", "cfg1_linemod_80", "cfg2_linemod_120x160", "cfg3_ycb_160", "cfg3_ycb_80x120",
+                                  "cfg3_ycb_240x320", "cfg3_ycb_480x640", "cfg5_n2000_240x320"])
 def test_posenet_forward_golden(name):
     g, (K, N, H, W, iters, wseed), o = _case(name)
     est, _ = _nets(K, N, wseed)
@@ -58,7 +59,8 @@ def test_posenet_forward_golden(name):
     assert int(c.view(-1).argmax()) == int(g["which_max"][0])
 
 
-@pytest.mark.parametrize("name", ["tiny", "cfg2_linemod_120x160", "cfg3_ycb_160", "cfg3_ycb_80x120"])
+@pytest.mark.parametrize("name", ["tiny", "cfg2_linemod_120x160", "cfg3_ycb_160", "cfg3_ycb_80x120", "cfg3_ycb_240x320",
+                                  "cfg3_ycb_480x640", "cfg5_n2000_240x320"])
 def test_estimate_poses_golden(name):
     """df_estimate_poses == the eval loop of the reference (tools/eval_ycb.py:192-229), ADD <= 1e-4 m."""
     from densefusion_amd.lib.network import PoseEstimator
@@ -283,3 +285,23 @@ def test_multi_bucket_call_equals_per_bucket_calls():
     assert _add(pose[5].cpu().numpy(), opose, bs[2]["model_points"][0]) < ADD_TOL
     with pytest.raises(RuntimeError):
         pe.estimate_multi([T(bs[0], "img")], cat("cloud"), cat("choose"), cat("obj"), 2)      # object counts disagree
+
+
+def test_layer_taps_match_the_references_intermediates():
+    """The engine's debug taps (df_net_debug_taps) against the 10 intermediates the imported reference produced for the tiny
+    config (forward hooks in oracle/make_golden.py): a regression localises to a layer.  up_3 exists at the chosen pixels only."""
+    g, (K, N, H, W, iters, wseed), o = _case("tiny")
+    est, _ = _nets(K, N, wseed)
+    est.debug_taps(True)
+    T = lambda k: torch.from_numpy(o[k])[None].cuda()
+    est(T("img"), T("cloud"), torch.from_numpy(o["choose"]).cuda(), torch.from_numpy(o["obj"]).cuda())
+    for name in ("stem", "layer1", "layer2", "layer3", "layer4", "psp", "up_1", "up_2"):
+        got = est.debug_tap(name).permute(0, 3, 1, 2)                     # NHWC -> the reference's NCHW
+        _close(got, g["tap_" + name])
+    _close(est.debug_tap("ap_x").reshape(1, 1024, 1), g["tap_ap_x"])
+    up3 = est.debug_tap("up_3")[0, :N, :, 0]                              # [N][64] rows of the chosen pixels
+    want = torch.from_numpy(g["tap_up_3"])[0].reshape(64, H * W)[:, torch.from_numpy(o["choose"]).reshape(-1)].T
+    _close(up3, want)
+    est.debug_taps(False)
+    with pytest.raises(RuntimeError):
+        est.debug_tap("psp")

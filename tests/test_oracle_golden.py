@@ -32,7 +32,8 @@ def _close(a, b, rtol=2e-5):
     assert np.abs(a - b).max() <= rtol * scale, (np.abs(a - b).max(), scale)
 
 
-@pytest.mark.parametrize("name", ["tiny", "cfg1_linemod_80", "cfg2_linemod_120x160", "cfg3_ycb_80x120"])
+@pytest.mark.parametrize("name", ["tiny", "cfg1_linemod_80", "cfg2_linemod_120x160", "cfg3_ycb_80x120", "cfg3_ycb_160",
+                                  "cfg3_ycb_240x320", "cfg3_ycb_480x640", "cfg5_n2000_240x320"])
 def test_posenet_forward_matches_reference(name):
     g, sd, sr, args, iters = _case(name)
     taps = {}
@@ -44,7 +45,8 @@ def test_posenet_forward_matches_reference(name):
             _close(taps[k[4:]].reshape(g[k].shape), g[k])
 
 
-@pytest.mark.parametrize("name", ["tiny", "cfg2_linemod_120x160", "cfg3_ycb_80x120"])
+@pytest.mark.parametrize("name", ["tiny", "cfg2_linemod_120x160", "cfg3_ycb_80x120", "cfg3_ycb_160", "cfg3_ycb_240x320",
+                                  "cfg3_ycb_480x640", "cfg5_n2000_240x320"])
 def test_eval_loop_matches_reference(name):
     g, sd, sr, args, iters = _case(name)
     with torch.no_grad():
@@ -147,3 +149,25 @@ def test_segnet_restatement_matches_reference_golden():
         y = segnet_ref.segnet_forward(sd, torch.from_numpy(g["x"])).numpy()
     assert y.shape == (2, 22, 32, 64)
     assert np.abs(y - g["logits"]).max() <= 1e-5 * np.abs(g["logits"]).max()
+
+
+def test_training_gradients_match_the_references_backward():
+    """Autograd through the oracle restatement == the imported reference's own Loss(...).backward() through its PoseNet
+    (tests/golden/grad_tiny.npz, oracle/make_golden.py::run_grad: non-symmetric idx, eval-mode dropout)."""
+    from oracle.make_golden import grad_sample
+    g = np.load(os.path.join(G, "grad_tiny.npz"))
+    K, N, H, W, M, wseed, iseed, idx0 = [int(v) for v in g["meta"]]
+    sd = {k: torch.from_numpy(v).clone().requires_grad_() for k, v in synth.make_state_dict(synth.posenet_spec(K), wseed).items()}
+    o = synth.make_object(iseed, H, W, N, K, num_points_mesh=M)
+    idx = torch.tensor([[idx0]])
+    T = lambda k: torch.from_numpy(o[k])[None]
+    r, t, c, emb = dfnet.posenet_forward(sd, T("img"), T("cloud"), torch.from_numpy(o["choose"]), idx)
+    loss, dis = loss_ref.loss_calculation(r, t, c, T("target"), T("model_points"), idx, T("cloud"), 0.015, False, M, [1])[:2]
+    _close(r.detach(), g["out_rx"]); _close(c.detach(), g["out_cx"])
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=2e-5)
+    np.testing.assert_allclose(float(dis), float(g["dis"]), rtol=2e-5)
+    loss.backward()
+    keys = [k[5:] for k in g.files if k.startswith("grad:")]
+    assert len(keys) == 20
+    for k in keys:
+        _close(grad_sample(sd[k].grad.numpy()), g["grad:" + k], rtol=5e-4)

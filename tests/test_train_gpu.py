@@ -156,3 +156,32 @@ def test_batched_training_pass_equals_separate_passes():
     assert set(h1) == set(h2) and len(h1) >= 20
     for k in h1:
         _close(h1[k], h2[k].cpu(), 5e-4, k)
+
+
+def test_training_gradients_match_the_references_backward():
+    """The HIP training path against the imported reference's own Loss(...).backward() through its PoseNet
+    (tests/golden/grad_tiny.npz, oracle/make_golden.py::run_grad: non-symmetric idx, dropout off)."""
+    import os
+    from densefusion_amd.lib import train_graph
+    from densefusion_amd.lib.loss import Loss
+    from densefusion_amd.lib.network import PoseNet
+    from oracle.make_golden import grad_sample
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "grad_tiny.npz"))
+    K, N, H, W, M, wseed, iseed, idx0 = [int(v) for v in g["meta"]]
+    o = synth.make_object(iseed, H, W, N, K, num_points_mesh=M)
+    idx = torch.tensor([[idx0]])
+    T = lambda k: torch.from_numpy(o[k])[None].cuda()
+    net = PoseNet(N, K)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.posenet_spec(K), wseed).items()})
+    net.cuda().train()
+    r, t, c, emb = train_graph.posenet_forward(net, T("img"), T("cloud"), torch.from_numpy(o["choose"]).cuda(), idx.cuda(), dropout=False)
+    loss, dis = Loss(M, [1])(r, t, c, T("target"), T("model_points"), idx.cuda(), T("cloud"), 0.015, False)[:2]
+    _close(r, torch.from_numpy(g["out_rx"]), 2e-4, "out_rx"); _close(c, torch.from_numpy(g["out_cx"]), 2e-4, "out_cx")
+    _close(loss, torch.from_numpy(g["loss"]), 1e-4, "loss"); _close(dis, torch.from_numpy(g["dis"]).reshape(dis.shape), 1e-4, "dis")
+    loss.backward()
+    params = dict(net.named_parameters())
+    keys = [k[5:] for k in g.files if k.startswith("grad:")]
+    assert len(keys) == 20
+    for k in keys:
+        got = torch.from_numpy(grad_sample(params[k].grad.cpu().numpy()))
+        _close(got, torch.from_numpy(g["grad:" + k]), 2e-3, k)
