@@ -64,7 +64,7 @@ def preprocess_objects(rgb, depth, label, objects, num_points, cam=YCB_CAM):
         desc[i, :6] = (frame, itemid, rmin, rmax, cmin, cmax)
         desc[i, 6] = np.array([seed & 0xFFFFFFFF], dtype=np.uint32).view(np.int32)[0]      # uint32 seed bits
     dev = rgb.device
-    d_desc = torch.from_numpy(desc).to(dev)
+    d_desc = torch.from_numpy(desc).pin_memory().to(dev, non_blocking=True)      # pinned: the upload does not wait for the stream
     rgb, label = rgb.contiguous(), label.to(torch.int32).contiguous()
     depth = depth.contiguous()
     if depth.dtype not in (torch.int16, torch.uint16):

@@ -70,3 +70,31 @@ def test_eval_ycb_entry_point(tmp_path):
             add = pose_math.add_metric(pose_math.transform_model(got[idx], mp), pose_math.transform_model(pose, mp))
             add_wo = pose_math.add_metric(pose_math.transform_model(got_wo[idx], mp), pose_math.transform_model(wo, mp))
             assert add < 1e-4 and add_wo < 1e-4, (fi, idx, add, add_wo)
+
+
+def test_eval_ycb_results_do_not_depend_on_the_window(tmp_path):
+    """Detections bucketed by crop size ACROSS a window of frames and run as one device call give, file for file, the
+    .mat results of the frame-by-frame path; a degenerate PoseCNN box is written as a lost detection (zero pose,
+    tools/eval_ycb.py:234-237) instead of aborting the run."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import eval_ycb
+    rng = np.random.default_rng(9)
+    K, N = 21, 1000
+    root, toolbox, cfg, frames, sdp, sdr = _fabricate(tmp_path, rng, 5, K, N)
+    # frame 1 gets a third, degenerate detection (x2 <= x1 + 2)
+    meta_path = toolbox / "results_PoseCNN_RSS2018" / "000001.mat"
+    meta = scio.loadmat(meta_path)
+    rois = np.vstack([meta["rois"], [0, 5, 100, 50, 101, 120, 0.3]])
+    scio.savemat(meta_path, {"labels": meta["labels"], "rois": rois})
+    outs = {}
+    for window in (1, 4):
+        wo, ref = tmp_path / f"wo{window}", tmp_path / f"ref{window}"
+        eval_ycb.main(["--dataset_root", str(root), "--model", str(tmp_path / "pose_model.pth"), "--refine_model",
+                       str(tmp_path / "pose_refine_model.pth"), "--dataset_config_dir", str(cfg), "--ycb_toolbox_dir", str(toolbox),
+                       "--result_wo_refine_dir", str(wo), "--result_refine_dir", str(ref), "--seed", "3", "--window", str(window),
+                       "--workers", "3"])
+        outs[window] = [(scio.loadmat(wo / f"{fi:04d}.mat")["poses"], scio.loadmat(ref / f"{fi:04d}.mat")["poses"]) for fi in range(5)]
+    for fi in range(5):
+        for a, b in zip(outs[1][fi], outs[4][fi]):
+            assert a.shape == b.shape and np.array_equal(a, b), fi
+    assert outs[4][1][1].shape == (3, 7) and not outs[4][1][1][2].any() and outs[4][1][1][0].any()

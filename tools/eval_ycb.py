@@ -10,15 +10,19 @@ PoseNet + arg-max selection + ``iteration`` refine steps as one device call (Pos
 (tools/eval_ycb.py:136-240), which the YCB toolbox scripts -- or densefusion_amd.lib.ycb_eval -- consume.
 
 Differences from the reference script: constants are flags with the reference's values as defaults; the
-random pixel subset follows the documented key rule instead of np.random (include/dfusion.h); objects of
-one frame that share a crop size go through the network as one batch; a detection without mask pixels is
-reported as lost (zero pose), like the reference's ZeroDivisionError branch (:234-237).
+random pixel subset follows the documented key rule instead of np.random (include/dfusion.h); a detection without
+mask pixels, or with a degenerate box, is reported as lost (zero pose), like the reference's ZeroDivisionError branch
+(:234-237).  Throughput: the keyframes are taken ``--window`` at a time (densefusion_amd.lib.eval_window): PNG decoding
+runs in ``--workers`` threads one window ahead, a window's frames go up in one copy that overlaps the previous window's
+compute, and ALL detections of the window -- bucketed by snapped crop size across its frames -- run through the network
+in one device call.  The result files do not depend on the window length (tests/test_eval_ycb_tool_gpu.py).
 """
 from __future__ import annotations
 
 import argparse
 import os
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import scipy.io as scio
@@ -26,8 +30,8 @@ import torch
 from PIL import Image
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from densefusion_amd.lib import preprocess as pp  # noqa: E402
-from densefusion_amd.lib.network import PoseEstimator, PoseNet, PoseRefineNet  # noqa: E402
+from densefusion_amd.lib.eval_window import WindowEstimator  # noqa: E402
+from densefusion_amd.lib.network import PoseNet, PoseRefineNet  # noqa: E402
 
 
 def read_lines(path):
@@ -54,6 +58,8 @@ def build_parser():
     ap.add_argument("--iteration", type=int, default=2)
     ap.add_argument("--max_frames", type=int, default=0, help="0 = all keyframes of test_data_list.txt")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--window", type=int, default=32, help="keyframes per device call (1 = frame by frame)")
+    ap.add_argument("--workers", type=int, default=8, help="PNG / .mat reader threads")
     return ap
 
 
@@ -72,7 +78,6 @@ def main(argv=None):
     refiner.to(dev)
     refiner.load_state_dict(torch.load(opt.refine_model, map_location=dev, weights_only=True))
     refiner.eval()
-    pe = PoseEstimator(estimator, refiner)
 
     testlist = read_lines(os.path.join(opt.dataset_config_dir, "test_data_list.txt"))
     if opt.max_frames > 0:
@@ -80,39 +85,60 @@ def main(argv=None):
     print(len(testlist))
     os.makedirs(opt.result_wo_refine_dir, exist_ok=True)
     os.makedirs(opt.result_refine_dir, exist_ok=True)
+    mine = [now for now in range(len(testlist)) if now % world == rank]
+    window = max(1, opt.window)
+    windows = [mine[i:i + window] for i in range(0, len(mine), window)]
+    if not windows:
+        return
+    IH, IW = 480, 640
+    we = WindowEstimator(estimator, refiner, opt.num_points, opt.iteration, window, (IH, IW))
+    # three pinned host slots: one being filled by the reader threads, one uploading, one whose upload may still be in flight
+    host = [dict(rgb=torch.empty(window, IH, IW, 3, dtype=torch.uint8).pin_memory(),
+                 depth=torch.empty(window, IH, IW, dtype=torch.int16).pin_memory(),
+                 label=torch.empty(window, IH, IW, dtype=torch.int32).pin_memory()) for _ in range(3)]
+    pool = ThreadPoolExecutor(max_workers=max(1, opt.workers))
 
-    for now, rel in enumerate(testlist):
-        if now % world != rank:
-            continue
-        rgb = np.array(Image.open("{0}/{1}-color.png".format(opt.dataset_root, rel)))[:, :, :3]
-        depth = np.array(Image.open("{0}/{1}-depth.png".format(opt.dataset_root, rel))).astype(np.uint16)
+    def read_frame(slot, f, now):
+        rel = testlist[now]
+        h = host[slot]
+        np.copyto(h["rgb"][f].numpy(), np.array(Image.open("{0}/{1}-color.png".format(opt.dataset_root, rel)))[:, :, :3])
+        np.copyto(h["depth"][f].numpy(), np.array(Image.open("{0}/{1}-depth.png".format(opt.dataset_root, rel))).astype(np.uint16).view(np.int16))
         meta = scio.loadmat("{0}/results_PoseCNN_RSS2018/{1}.mat".format(opt.ycb_toolbox_dir, "%06d" % now))
-        label = np.array(meta["labels"]).astype(np.int32)
-        rois = np.array(meta["rois"])
-        d_rgb = torch.from_numpy(np.ascontiguousarray(rgb))[None].to(dev)
-        d_depth = torch.from_numpy(depth.view(np.int16))[None].to(dev)
-        d_label = torch.from_numpy(label)[None].to(dev)
-        n = rois.shape[0]
-        wo = np.zeros((n, 7))
-        refined = np.zeros((n, 7))
-        groups = {}
-        for idx in range(n):
-            bb = pp.get_bbox(rois[idx])
-            groups.setdefault((bb[1] - bb[0], bb[3] - bb[2]), []).append((idx, int(rois[idx][1]), bb))
-        for (H, W), members in groups.items():
-            objs = [(0, itemid, bb, opt.seed + now * 64 + idx) for idx, itemid, bb in members]
-            img, cloud, choose, count = pp.preprocess_objects(d_rgb, d_depth, d_label, objs, opt.num_points)
-            index = torch.tensor([itemid - 1 for _, itemid, _ in members], dtype=torch.int64, device=dev)
-            p_wo, p_ref = pe.estimate(img, cloud, choose, index, opt.iteration)
-            p_wo, p_ref, count = p_wo.cpu().numpy(), p_ref.cpu().numpy(), count.cpu().numpy()
-            for k, (idx, itemid, _) in enumerate(members):
-                if count[k] == 0:
-                    print("PoseCNN Detector Lost {0} at No.{1} keyframe".format(itemid, now))
-                    continue                                  # zero pose rows, like the reference
-                wo[idx], refined[idx] = p_wo[k], p_ref[k]
-        scio.savemat("{0}/{1}.mat".format(opt.result_wo_refine_dir, "%04d" % now), {"poses": wo.tolist()})
-        scio.savemat("{0}/{1}.mat".format(opt.result_refine_dir, "%04d" % now), {"poses": refined.tolist()})
-        print("Finish No.{0} keyframe".format(now))
+        np.copyto(h["label"][f].numpy(), np.array(meta["labels"]).astype(np.int32))
+        return np.array(meta["rois"])
+
+    def start_read(wi):
+        return [pool.submit(read_frame, wi % 3, f, now) for f, now in enumerate(windows[wi])]
+
+    def finish(wi, handle, rois_per_frame):
+        wo, refined, lost = we.collect(handle)
+        k = 0
+        for now, rois in zip(windows[wi], rois_per_frame):
+            n = rois.shape[0]
+            for idx in range(n):
+                if lost[k + idx]:
+                    print("PoseCNN Detector Lost {0} at No.{1} keyframe".format(int(rois[idx][1]), now))
+            scio.savemat("{0}/{1}.mat".format(opt.result_wo_refine_dir, "%04d" % now), {"poses": wo[k:k + n].tolist()})
+            scio.savemat("{0}/{1}.mat".format(opt.result_refine_dir, "%04d" % now), {"poses": refined[k:k + n].tolist()})
+            print("Finish No.{0} keyframe".format(now))
+            k += n
+
+    reads = {0: start_read(0)}
+    pending = None
+    for wi in range(len(windows)):
+        rois_per_frame = [f.result() for f in reads.pop(wi)]
+        if wi + 1 < len(windows):
+            reads[wi + 1] = start_read(wi + 1)            # decoded while this window uploads and computes
+        F = len(windows[wi])
+        h = host[wi % 3]
+        dets = [(f, int(rois[idx][1]), rois[idx], opt.seed + now * 64 + idx)
+                for f, (now, rois) in enumerate(zip(windows[wi], rois_per_frame)) for idx in range(rois.shape[0])]
+        handle = we.submit(h["rgb"][:F], h["depth"][:F], h["label"][:F], dets)       # enqueued, no host sync
+        if pending is not None:
+            finish(*pending)                             # the previous window's results, while this one runs
+        pending = (wi, handle, rois_per_frame)
+    finish(*pending)
+    pool.shutdown()
 
 
 if __name__ == "__main__":
