@@ -319,6 +319,71 @@ def bench_entry_point(est, ref, device, windows=6, frames=56):
                     "what tools/eval_ycb.py runs per --window, without PNG decoding / .mat writing"}
 
 
+def bench_train(device):
+    """BASELINE configs[3] per GPU: YCB training step, K=21, N=1000, M=500 (PoseNet phase), symmetric KNN loss on half of the
+    frames, 8 frames accumulated per optimizer step (tools/train.py:131-170), every layer's forward / data gradient / weight
+    gradient a HIP launch (densefusion_amd/lib/train_graph.py).  frames/s with the reference's bs = 1 passes and with the 8
+    frames of an accumulation window sharing one pass (same gradients); per-kernel-kind TFLOP/s from HIP events around the
+    conv launches of an instrumented pass."""
+    from densefusion_amd import train_ops, train_utils
+    from densefusion_amd.lib.loss import Loss
+    K, N, M, acc = K_OBJ, N_PTS, 500, 8
+    net = PoseNet(N, K)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.posenet_spec(K), WSEED).items()})
+    net.to(device).train()
+    flat = train_utils.FlatParams(net)
+    opt = train_utils.FlatAdam(flat, lr=1e-4)
+    crit = Loss(M, [12, 15, 18, 19, 20])
+    H, W = 160, 160
+    frames = []
+    for j in range(acc):
+        o = synth.make_object(500 + j, H, W, N, K, M)
+        o["obj"][0] = [12, 3, 15, 7][j % 4]                         # every other frame is a symmetric object (KNN loss branch)
+        frames.append({k: torch.from_numpy(v).to(device) for k, v in o.items()})
+
+    def step(fr):
+        img = torch.stack([f["img"] for f in fr]); cloud = torch.stack([f["cloud"] for f in fr])
+        choose = torch.stack([f["choose"] for f in fr]); obj = torch.stack([f["obj"] for f in fr])
+        r, t, c, emb = net(img, cloud, choose, obj)
+        loss = 0
+        for b, f in enumerate(fr):
+            loss = loss + crit(r[b:b + 1], t[b:b + 1], c[b:b + 1], f["target"][None], f["model_points"][None], f["obj"][None], f["cloud"][None],
+                               0.015, False)[0]
+        loss.backward()
+
+    def window(P):
+        for i in range(0, acc, P):
+            step(frames[i:i + P])
+        train_utils.allreduce_gradients(flat); opt.step(); flat.zero_grad()
+
+    out = {"workload": f"YCB training step, K={K}, N={N}, M={M}, crop {H}x{W}, {acc} frames per optimizer step, fp32", "frames_per_s": {}}
+    for P in (1, acc):
+        window(P)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            window(P)
+        torch.cuda.synchronize()
+        out["frames_per_s"][f"{P}_per_pass"] = round(reps * acc / (time.perf_counter() - t0), 1)
+    kinds, whole = {}, {}
+    for P in (1, acc):
+        train_ops.profile_begin()
+        window(P)
+        prof = train_ops.profile_end()
+        for kind, (ms, fl, n) in prof.items():
+            kinds.setdefault(kind, {})[f"{P}_per_pass"] = {"ms_per_window": round(ms, 3), "launches": n, "tflops": round(fl / ms / 1e9, 2) if ms > 0 else 0.0,
+                                                           "frac": round(fl / ms / 1e9 / FP32_PEAK_TFLOPS, 4) if ms > 0 else 0.0}
+        # the whole step against the matrix peak: FLOPs of the three conv kernel kinds / wall time of an optimizer window
+        wall_s = acc / out["frames_per_s"][f"{P}_per_pass"]
+        fl = sum(v[1] for v in prof.values())
+        whole[f"{P}_per_pass"] = {"conv_gflop_per_frame": round(fl / acc / 1e9, 1), "tflops_wall": round(fl / wall_s / 1e12, 2),
+                                  "frac_of_mfma_peak": round(fl / wall_s / 1e12 / FP32_PEAK_TFLOPS, 4)}
+    out["conv_kernels"] = kinds
+    out["whole_step"] = whole
+    return out
+
+
 def host_threads():
     """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota (a GPU box
     exposes all host cores in os.cpu_count() but grants a 16-core share per GPU)."""
@@ -528,6 +593,7 @@ def main():
             out["knn"]["symmetric_loss_forward"] = bench_loss()
             out["latency_single_object"] = bench_latency(est, ref, device)
             out["entry_point"] = bench_entry_point(est, ref, device)
+            out["train"] = bench_train(device)
         if world == 1 and not args.no_cpu_baseline:
             gpu_poses = bucket_poses(buckets, groups)
             out["cpu_baseline"], out["parity"] = cpu_baseline(buckets, gpu_poses)

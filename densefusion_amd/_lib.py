@@ -67,7 +67,8 @@ SIGNATURES = {
     "df_conv3x3_winograd_scratch_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "df_conv3x3_winograd_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, ctypes.c_size_t, _vp]),
     "df_conv2d_dgrad_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),
-    "df_conv2d_wgrad_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    "df_conv2d_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "df_conv2d_wgrad_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "df_net_debug_taps": (_i, [_vp, _i]),
     "df_net_debug_tap_read": (_i, [_vp, ctypes.c_char_p, _vp, _i64, ctypes.POINTER(_i64)]),
     "df_net_profile": (_i, [_vp, _i]),

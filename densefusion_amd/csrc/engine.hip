@@ -1119,14 +1119,17 @@ extern "C" int df_conv2d_dgrad_nhwc(const df_conv_desc *d, const float *dy, floa
   return launch_conv(q, st);
 }
 
-extern "C" int df_conv2d_wgrad_nhwc(const df_conv_desc *d, const float *dy, float *dw, float *db, df_stream_t stream) {
+extern "C" size_t df_conv2d_wgrad_workspace_bytes(const df_conv_desc *d) {
+  ConvParams f;
+  if (conv_desc_to_params(d, f, "conv2d_wgrad_workspace_bytes") != DF_OK) return 0;
+  return wgrad_workspace_bytes(f);
+}
+
+extern "C" int df_conv2d_wgrad_nhwc(const df_conv_desc *d, const float *dy, float *dw, float *db, void *ws, size_t ws_bytes, df_stream_t stream) {
   ConvParams f;
   int rc = conv_desc_to_params(d, f, "conv2d_wgrad");
   if (rc != DF_OK) return rc;
   if (!dy || !dw || !f.in) return set_error(DF_ERR_ARG, "conv2d_wgrad: null pointer");
-  hipStream_t st = to_stream(stream);
   f.out = const_cast<float *>(dy);
-  hipMemsetAsync(dw, 0, (size_t)f.Cout * f.KH * f.KW * f.Cin * sizeof(float), st);
-  if (db) hipMemsetAsync(db, 0, (size_t)f.Cout * sizeof(float), st);
-  return launch_wgrad(f, dw, db, st);
+  return launch_wgrad(f, dw, db, ws, ws_bytes, to_stream(stream));
 }

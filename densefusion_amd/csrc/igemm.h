@@ -33,6 +33,9 @@ struct ConvParams {
   int zcount = 1;
   int ngroup = 0;   // column tiles per L2-resident weight group (0 = one group); set by launch_conv
   long z_in_coff = 0, z_wgt = 0, z_bias = 0, z_out_coff = 0;
+  // magic pairs for the kernels' divisions by OH*OW and OW (set by the launchers)
+  unsigned ohw_magic = 0, ow_magic = 0;
+  int ohw_sh = 0, ow_sh = 0;
 };
 
 // number of colsum partial rows a launch with these params writes (so callers can size the buffer)
@@ -44,7 +47,9 @@ double conv_bytes(const ConvParams &p);
 int launch_conv(const ConvParams &p, hipStream_t st);
 
 // dW[n][(ky,kx,c)] += sum_m dY[m][n] * A[m][(ky,kx,c)]  (A = the im2col view of x of the forward conv `p`; p.out = dY)
-// dw must be zeroed by the caller; db (optional) += column sums of dY
-int launch_wgrad(const ConvParams &p, float *dw, float *db, hipStream_t st);
+// dw / db (optional: column sums of dY) are overwritten.  The pixel range is split over workgroups; the partial tiles go to `ws`
+// (wgrad_workspace_bytes) and are added in a fixed order: bit-reproducible, no atomics.
+size_t wgrad_workspace_bytes(const ConvParams &p);
+int launch_wgrad(const ConvParams &p, float *dw, float *db, void *ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace df

@@ -37,6 +37,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 32;
 constexpr int LDK = 36;   // padded LDS row (floats): 16 lanes x 16 B land on 64 distinct banks
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// n / d for 0 <= n < 2^31 with a host-made magic pair (make_fdiv): one v_mul_hi + shift instead of ~40 instructions
+__device__ __forceinline__ int fdiv(int n, unsigned magic, int sh, int d) {
+  return d == 1 ? n : (int)(__umulhi((unsigned)n, magic) >> sh);
+}
+
+// magic = ceil(2^(31+L) / d) with 2^(L-1) < d <= 2^L: exact for every n < 2^31 (error term n * (magic*d - 2^(31+L)) < 2^(31+L))
+void make_fdiv(long d, unsigned &magic, int &sh) {
+  magic = 0; sh = 0;
+  if (d <= 1) return;
+  int L = 0;
+  while ((1L << L) < d) ++L;
+  magic = (unsigned)((((unsigned __int128)1 << (31 + L)) + (unsigned long)d - 1) / (unsigned long)d);
+  sh = L - 1;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void igemm_f32_kernel(const ConvParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -220,8 +237,6 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const ConvParams p) {
 //   * epilogue through LDS: each wave transposes its accumulators so that global stores / residual
 //     loads are 16-byte vectors covering whole 128/256-byte row segments.
 // ------------------------------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT>
 __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -509,8 +524,10 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
 // Weight gradient: dW[n][k] += sum_m dY[m][n] * A[m][k], k = (ky,kx,c), A = im2col view of the forward input.
 // A GEMM whose reduction runs over the pixels m: both operands are staged [m][channel] (16-B vectors along
 // the contiguous channel axis), the MFMA takes one m pair per step with lanes along n (A operand) and along
-// k (B operand) -- plain ds_read_b32, conflict-free -- and the pixel range is split over blockIdx.z with
-// fp32 atomics combining the partial tiles.  64x64 output tile, 4 waves x one 32x32 accumulator.
+// k (B operand) -- plain ds_read_b32, conflict-free -- and the pixel range is split over blockIdx.z; every (tile, z)
+// workgroup stores its partial tile to its own slice of `dw` ([split][Cout][K]) and wgrad_reduce_kernel adds the slices in a
+// fixed order (bit-reproducible gradients, no atomics).  64x64 output tile, 4 waves x one 32x32 accumulator: the small-shape
+// fallback of wgrad_f32_v2_kernel (Cout < 128 or K < 128).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const ConvParams p, float *__restrict__ dw, int m_chunk) {
   constexpr int TN_ = 64, TK_ = 64, RM = 32, LDS_LD = 68;
@@ -588,11 +605,160 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const ConvParams p, floa
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int n = n0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, k = k0 + wn * 32 + li;
-    if (n < p.Cout && k < K) atomicAdd(dw + (size_t)n * K + k, acc[e]);
+    if (n < p.Cout && k < K) dw[((size_t)blockIdx.z * p.Cout + n) * K + k] = acc[e];
   }
 }
 
-// db[c] += sum_m dY[m][c]
+// ------------------------------------------------------------------------------------------------
+// Weight gradient, large shapes: 128 (n) x 128 (k) output tile, 4 waves x (2 x 2) 32x32 accumulators, pixel chunks of 32
+// through a double-buffered LDS tile with the next chunk's global loads in flight (the forward kernel's pipeline, with the
+// contraction over the pixel axis).  Both operands are staged as [pixel][channel] rows (16-byte global loads along the
+// contiguous channel axis, ds_write_b128); the MFMA takes two pixels per step with lanes along n (A operand, dY) and along k
+// (B operand, the im2col view of x): fragment reads are ds_read(2)_b32 over 32 consecutive floats of a row.  The n side of
+// the tile is 128 or 64 (Cout = 64 layers: up_2, up_3, layer1).  Every out-of-range element
+// (pixels beyond the chunk, padding taps, ragged Cout / K) is a bounds-checked buffer load that returns 0.
+// ------------------------------------------------------------------------------------------------
+template <int TN_>
+__global__ __launch_bounds__(256) void wgrad_f32_v2_kernel(const ConvParams p, float *__restrict__ part, int m_chunk) {
+  static_assert(TN_ == 64 || TN_ == 128, "n side of the tile");
+  constexpr int TK_ = 128, RM = 32;
+  constexpr int LDY = TN_ + 4, LDA = TK_ + 4;        // row strides: the second pixel of a step lands 4 banks further (2-way at worst)
+  constexpr int OPY = RM * LDY, OPA = RM * LDA;      // operand tiles (floats)
+  constexpr int NI = TN_ / 64;                       // 32x32 accumulators per wave along n
+  constexpr int VY = TN_ / 4, RPY = 256 / VY, PY = RM / RPY;      // dY loader: vectors per row, rows per pass, passes
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // [2 buffers][dY tile | A tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int M = p.B * p.OH * p.OW, K = p.KH * p.KW * p.Cin;
+  const int tiles_k = (K + TK_ - 1) / TK_;
+  const int n0 = (blockIdx.x / tiles_k) * TN_, k0 = (blockIdx.x % tiles_k) * TK_;
+  const int m_begin = blockIdx.z * m_chunk, m_end = min(M, m_begin + m_chunk);
+  const int nt = (m_end - m_begin + RM - 1) / RM;
+
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, (unsigned)((size_t)p.B * p.H * p.W * p.in_ld * sizeof(float)), 0x00020000);
+  const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (unsigned)((size_t)M * p.out_ld * sizeof(float)), 0x00020000);
+
+  // loader of the A tile: this thread stages channel vector `vec` (4 floats) of the rows lrow + 8 i
+  const int vec = tid & 31, lrow = tid >> 5;
+  const int kcol = k0 + vec * 4;                     // fixed for the whole kernel: decode its tap once
+  const bool kok = kcol < K;
+  int c = kcol, dyy = 0, dxx = 0;
+  if (p.KH * p.KW > 1) {
+    const int tap = kcol / p.Cin;
+    c = kcol - tap * p.Cin;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    dyy = ky * p.dil; dxx = kx * p.dil;
+  }
+  // loader of the dY tile
+  const int yvec = tid % VY, yrow = tid / VY;
+  const int ncol = n0 + yvec * 4;
+  const bool nok = ncol < p.Cout;
+  const int ohw = p.OH * p.OW;
+  u32x4 ry[PY], ra[4];
+  auto issue_loads = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < PY; ++i) {
+      const int m = m_begin + t * RM + yrow + RPY * i;
+      unsigned o = (m < m_end && nok) ? (unsigned)(m * p.out_ld + p.out_coff + ncol) * 4u : 0xffffffffu;
+      asm("" : "+v"(o));
+      ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, o, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m_begin + t * RM + lrow + 8 * i;
+      const int b = fdiv(m, p.ohw_magic, p.ohw_sh, ohw), rem = m - b * ohw;
+      const int oy = fdiv(rem, p.ow_magic, p.ow_sh, p.OW), ox = rem - oy * p.OW;
+      const int iy = oy * p.stride - p.pad + dyy, ix = ox * p.stride - p.pad + dxx;
+      const bool aok = m < m_end && kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      unsigned o = aok ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff + c) * 4u : 0xffffffffu;
+      asm("" : "+v"(o));
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, o, 0, 0);
+    }
+  };
+  auto write_lds = [&](int buf) {
+    float *sY = smem + buf * (OPY + OPA), *sA = sY + OPY;
+#pragma unroll
+    for (int i = 0; i < PY; ++i) *reinterpret_cast<u32x4 *>(sY + (yrow + RPY * i) * LDY + yvec * 4) = ry[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4 *>(sA + (lrow + 8 * i) * LDA + vec * 4) = ra[i];
+  };
+  f32x16 acc[NI][2];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int li = lane & 31, lh = lane >> 5;
+  const int fy = lh * LDY + wn * (TN_ / 2) + li, fa = OPY + lh * LDA + wk * 64 + li;
+  if (nt > 0) {
+    issue_loads(0);
+    write_lds(0);
+    issue_loads(1);
+  }
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const float *base = smem + (t & 1) * (OPY + OPA);
+#pragma unroll
+    for (int s = 0; s < RM / 2; ++s) {
+      if (s == RM / 4) {               // mid-tile: hand the next chunk to the idle buffer, start the one after
+        write_lds((t & 1) ^ 1);
+        issue_loads(t + 2);
+      }
+      float a[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) a[i] = base[fy + s * 2 * LDY + i * 32];
+      const float b0 = base[fa + s * 2 * LDA], b1 = base[fa + s * 2 * LDA + 32];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b1, acc[i][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  float *dst = part + (size_t)blockIdx.z * p.Cout * K;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + wn * (TN_ / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, k = k0 + wk * 64 + j * 32 + li;
+        if (n < p.Cout && k < K) dst[(size_t)n * K + k] = acc[i][j][e];
+      }
+}
+
+// dw[i] = sum_z part[z][i], bit-reproducible: 8 z-lanes per output vector each add their slices z = l, l + 8, ... in ascending
+// order (8 independent load chains instead of one of length `split`), then the 8 partial sums meet in LDS and are added in
+// lane order.  32 float4 outputs per workgroup.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, long n4, int split) {
+  __shared__ f32x4 s_p[8][32];
+  const int col = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  for (long i0 = blockIdx.x * 32L; i0 < n4; i0 += (long)gridDim.x * 32) {
+    const long i = i0 + col;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4)
+      for (int z = zl; z < split; z += 8) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(part)[(long)z * n4 + i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += v[e];
+      }
+    s_p[zl][col] = a;
+    __syncthreads();
+    if (zl == 0 && i < n4) {
+#pragma unroll
+      for (int l = 1; l < 8; ++l)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += s_p[l][col][e];
+      reinterpret_cast<f32x4 *>(dw)[i] = a;
+    }
+    __syncthreads();
+  }
+}
+
+// part[blockIdx.y][c] = sum over the block's rows of dY[m][c]  (summed over the row blocks by bias_reduce_kernel)
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float *__restrict__ dy, int M, int C, int ld, int coff,
                                                         float *__restrict__ db, int rows_per_block) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
@@ -603,7 +769,24 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float *__restrict_
     for (int r = r0 + part; r < r1; r += 4) a += dy[(size_t)r * ld + coff + c];
   s[part][threadIdx.x & 63] = a;
   __syncthreads();
-  if (part == 0 && c < C) atomicAdd(db + c, (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]));
+  if (part == 0 && c < C) db[(size_t)blockIdx.y * C + c] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+}
+
+// db[c] = sum_b part[b][c]: 8 lanes per channel add b = l, l + 8, ... in ascending order, then meet in LDS in lane order
+__global__ __launch_bounds__(256) void bias_reduce_kernel(const float *__restrict__ part, float *__restrict__ db, int C, int nblk) {
+  __shared__ float s_p[8][32];
+  const int col = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + col;
+  float a = 0.f;
+  if (c < C)
+    for (int b = zl; b < nblk; b += 8) a += part[(size_t)b * C + c];
+  s_p[zl][col] = a;
+  __syncthreads();
+  if (zl == 0 && c < C) {
+#pragma unroll
+    for (int l = 1; l < 8; ++l) a += s_p[l][col];
+    db[c] = a;
+  }
 }
 
 
@@ -709,26 +892,72 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
   return check_launch("igemm");
 }
 
-int launch_wgrad(const ConvParams &p, float *dw, float *db, hipStream_t st) {
+namespace {
+struct WgradPlan { bool big; int tiles, split, chunk, nblk; size_t part_floats, bias_floats; };
+
+WgradPlan wgrad_plan(const ConvParams &p) {
+  WgradPlan w{};
+  const int M = p.B * p.OH * p.OW, K = p.KH * p.KW * p.Cin;
+  w.big = p.Cout >= 64 && K >= 128;
+  const int tn = w.big && p.Cout >= 128 ? 128 : 64, tk = w.big ? 128 : 64;
+  w.tiles = ((p.Cout + tn - 1) / tn) * ((K + tk - 1) / tk);
+  // split the pixel range so that ~1024 workgroups are in flight, each with at least 256 pixels
+  int split = (1024 + w.tiles - 1) / w.tiles;
+  const int max_split = (M + 255) / 256;
+  if (split > max_split) split = max_split;
+  if (split > 256) split = 256;          // (the partial slices are re-read by the reduction)
+  if (split < 1) split = 1;
+  w.chunk = ((M + split - 1) / split + 31) / 32 * 32;
+  w.split = (M + w.chunk - 1) / w.chunk;
+  w.nblk = (M + 127) / 128;
+  w.part_floats = w.split > 1 ? (size_t)w.split * p.Cout * K : 0;       // a single slice goes straight to dw
+  w.bias_floats = (size_t)w.nblk * p.Cout;
+  return w;
+}
+}  // namespace
+
+size_t wgrad_workspace_bytes(const ConvParams &p) {
+  const WgradPlan w = wgrad_plan(p);
+  return (w.part_floats + w.bias_floats) * sizeof(float);
+}
+
+int launch_wgrad(const ConvParams &p0, float *dw, float *db, void *ws, size_t ws_bytes, hipStream_t st) {
+  ConvParams p = p0;
   if (!p.in || !p.out || !dw) return set_error(DF_ERR_ARG, "wgrad: null pointer");
   if (p.Cin % 4 || p.in_ld % 4 || p.in_coff % 4 || p.out_ld % 4 || p.out_coff % 4 || p.Cout % 4)
     return set_error(DF_ERR_ARG, "wgrad: channel counts / strides / offsets must be multiples of 4");
   if (p.up != 1 || p.zcount != 1) return set_error(DF_ERR_ARG, "wgrad: input dilation / grouped launches not supported");
   const int M = p.B * p.OH * p.OW, K = p.KH * p.KW * p.Cin;
   if (M <= 0) return DF_OK;
-  const int tiles = ((p.Cout + 63) / 64) * ((K + 63) / 64);
-  // split the pixel range so that ~1024 workgroups are in flight, each with at least 256 pixels
-  int split = (1024 + tiles - 1) / tiles;
-  const int max_split = (M + 255) / 256;
-  if (split > max_split) split = max_split;
-  if (split < 1) split = 1;
-  const int chunk = ((M + split - 1) / split + 31) / 32 * 32;
-  split = (M + chunk - 1) / chunk;
-  hipLaunchKernelGGL(wgrad_f32_kernel, dim3(tiles, 1, split), dim3(256), 0, st, p, dw, chunk);
+  if ((size_t)p.B * p.H * p.W * p.in_ld * sizeof(float) >= (1ull << 32) || (size_t)M * p.out_ld * sizeof(float) >= (1ull << 32))
+    return set_error(DF_ERR_ARG, "wgrad: tensor too large (4 GB per operand)");
+  const WgradPlan w = wgrad_plan(p);
+  if (wgrad_workspace_bytes(p) > ws_bytes || (wgrad_workspace_bytes(p) && !ws)) return set_error(DF_ERR_WORKSPACE, "wgrad: workspace too small");
+  float *part = w.split > 1 ? static_cast<float *>(ws) : dw;
+  float *bpart = static_cast<float *>(ws) + w.part_floats;
+  make_fdiv((long)p.OH * p.OW, p.ohw_magic, p.ohw_sh);
+  make_fdiv(p.OW, p.ow_magic, p.ow_sh);
+  if (w.big) {
+    static bool attr_done[64] = {};
+    int dev = 0;
+    hipGetDevice(&dev);
+    constexpr size_t lds128 = (size_t)2 * 32 * (132 + 132) * 4, lds64 = (size_t)2 * 32 * (68 + 132) * 4;
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_f32_v2_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+      attr_done[dev] = true;
+    }
+    if (p.Cout >= 128) hipLaunchKernelGGL(wgrad_f32_v2_kernel<128>, dim3(w.tiles, 1, w.split), dim3(256), lds128, st, p, part, w.chunk);
+    else hipLaunchKernelGGL(wgrad_f32_v2_kernel<64>, dim3(w.tiles, 1, w.split), dim3(256), lds64, st, p, part, w.chunk);
+  } else {
+    hipLaunchKernelGGL(wgrad_f32_kernel, dim3(w.tiles, 1, w.split), dim3(256), 0, st, p, part, w.chunk);
+  }
+  if (w.split > 1) {
+    const long n4 = (long)p.Cout * K / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((n4 + 31) / 32, 8192)), dim3(256), 0, st, part, dw, n4, w.split);
+  }
   if (db) {
-    const int rpb = 512;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3((p.Cout + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, st, p.out, M, p.Cout, p.out_ld,
-                       p.out_coff, db, rpb);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((p.Cout + 63) / 64, w.nblk), dim3(256), 0, st, p.out, M, p.Cout, p.out_ld, p.out_coff, bpart, 128);
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3((p.Cout + 31) / 32), dim3(256), 0, st, bpart, db, p.Cout, w.nblk);
   }
   return check_launch("wgrad");
 }

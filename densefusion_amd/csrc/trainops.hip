@@ -225,10 +225,26 @@ __global__ __launch_bounds__(TB) void scatter_add_rows_kernel(const float *__res
 }
 
 // mean over rows (AvgPool1d over the points) and its adjoint
-__global__ __launch_bounds__(TB) void colmean_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long rows, int C) {
-  GRID_STRIDE(c, (long)C) {
-    float s = 0.f;
-    for (long r = 0; r < rows; ++r) s += x[r * C + c];
+// 32 channels per workgroup x 8 row lanes: lane l adds rows l, l + 8, ... in ascending order (four loads in flight), the 8
+// partial sums meet in LDS and are added in lane order (fixed order: deterministic)
+__global__ __launch_bounds__(256) void colmean_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long rows, int C) {
+  __shared__ float s_p[8][32];
+  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + col;
+  float s = 0.f;
+  if (c < C) {
+    long r = rl;
+    for (; r + 24 < rows; r += 32) {
+      const float v0 = x[r * C + c], v1 = x[(r + 8) * C + c], v2 = x[(r + 16) * C + c], v3 = x[(r + 24) * C + c];
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; r < rows; r += 8) s += x[r * C + c];
+  }
+  s_p[rl][col] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+#pragma unroll
+    for (int l = 1; l < 8; ++l) s += s_p[l][col];
     y[c] = s / (float)rows;
   }
 }
@@ -305,7 +321,7 @@ extern "C" int df_gather_rows(const float *in, const int64_t *idx, float *out, i
 }
 extern "C" int df_colmean(const float *in, float *out, int64_t rows, int C, int backward, df_stream_t stream) {
   NN(in); NN(out);
-  if (!backward) hipLaunchKernelGGL(colmean_fwd_kernel, dim3(nblk(C)), dim3(TB), 0, ST, in, out, (long)rows, C);
+  if (!backward) hipLaunchKernelGGL(colmean_fwd_kernel, dim3((C + 31) / 32), dim3(256), 0, ST, in, out, (long)rows, C);
   else hipLaunchKernelGGL(colmean_bwd_kernel, dim3(nblk(rows * C)), dim3(TB), 0, ST, in, out, (long)rows, C);
   return check_launch("colmean");
 }

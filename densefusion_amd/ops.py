@@ -78,9 +78,17 @@ class ConvNHWC(torch.autograd.Function):
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                 dw = torch.empty_like(w)
                 db = torch.empty(w.shape[0], device=x.device) if has_bias else None
-                _lib.check(L.df_conv2d_wgrad_nhwc(ctypes.byref(d), dy.data_ptr(), dw.data_ptr(),
-                                                  db.data_ptr() if db is not None else None, _lib.current_stream()), "conv2d_wgrad")
+                wgrad(d, dy, dw, db)
         return dx, dw, db, None, None, None
+
+
+def wgrad(d, dy, dw, db):
+    """``df_conv2d_wgrad_nhwc`` with its split-pixel workspace (deterministic two-pass reduction)."""
+    L = _lib.lib()
+    need = L.df_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(int(need), 4), dtype=torch.uint8, device=dy.device)
+    _lib.check(L.df_conv2d_wgrad_nhwc(ctypes.byref(d), dy.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                      ws.data_ptr(), ws.numel(), _lib.current_stream()), "conv2d_wgrad")
 
 
 def conv3x3_winograd_nhwc(x, w, bias=None, dil=1, act=0, res=None):

@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .ops import _desc, conv2d_nhwc
+from .ops import _desc, conv2d_nhwc, wgrad
 
 
 def _st():
@@ -18,6 +18,45 @@ def _ck(rc, what):
     _lib.check(rc, what)
 
 
+# optional per-launch timing of the three MFMA kernels of a training step (bench.py `train` object): events on the launch stream
+_PROFILE = None
+
+
+def profile_begin():
+    """Arm per-launch timing of the conv forward / data-gradient / weight-gradient launches (HIP events on the current stream)."""
+    global _PROFILE
+    _PROFILE = {"fwd": [], "dgrad": [], "wgrad": []}
+
+
+def profile_end():
+    """-> {kind: (milliseconds, FLOPs, launches)} since profile_begin(); synchronises."""
+    global _PROFILE
+    prof, _PROFILE = _PROFILE, None
+    torch.cuda.synchronize()
+    return {k: (sum(a.elapsed_time(b) for a, b, _ in v), sum(f for _, _, f in v), len(v)) for k, v in prof.items()}
+
+
+class _Timed:
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _PROFILE is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _PROFILE[self.kind].append((self.a, b, self.flops))
+        return False
+
+
+def _conv_flops(x, w, y):
+    return 2.0 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
+
+
 class ConvAct(torch.autograd.Function):
     """y = act(conv(x, w) + bias + res): ONE fused MFMA launch forward; backward = activation gradient kernel, then the
     data-gradient (same MFMA kernel, flipped weights) and weight/bias-gradient MFMA kernels."""
@@ -25,8 +64,12 @@ class ConvAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, res, slope, stride, pad, dil, act):
         x, w = x.contiguous(), w.contiguous()
-        y = conv2d_nhwc(x, w, bias, stride=stride, pad=pad, dil=dil, act=act, res=res.contiguous() if res is not None else None,
-                        prelu=slope)
+        with _Timed("fwd", 0.0) as _t:
+            y = conv2d_nhwc(x, w, bias, stride=stride, pad=pad, dil=dil, act=act, res=res.contiguous() if res is not None else None,
+                            prelu=slope)
+        if _PROFILE is not None and _PROFILE["fwd"]:
+            a, b, _ = _PROFILE["fwd"][-1]
+            _PROFILE["fwd"][-1] = (a, b, _conv_flops(x, w, y))
         ctx.save_for_backward(x, w, y, slope if slope is not None else torch.empty(0, device=x.device))
         ctx.cfg = (stride, pad, dil, act, bias is not None, res is not None, slope is not None)
         return y
@@ -52,12 +95,13 @@ class ConvAct(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 scratch = torch.empty_like(w)
-                _ck(L.df_conv2d_dgrad_nhwc(ctypes.byref(d), g.data_ptr(), dx.data_ptr(), scratch.data_ptr(), 0, _st()), "conv2d_dgrad")
+                with _Timed("dgrad", _conv_flops(x, w, y)):
+                    _ck(L.df_conv2d_dgrad_nhwc(ctypes.byref(d), g.data_ptr(), dx.data_ptr(), scratch.data_ptr(), 0, _st()), "conv2d_dgrad")
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                 dw = torch.empty_like(w)
                 db = torch.empty(w.shape[0], device=x.device) if has_bias else None
-                _ck(L.df_conv2d_wgrad_nhwc(ctypes.byref(d), g.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, _st()),
-                    "conv2d_wgrad")
+                with _Timed("wgrad", _conv_flops(x, w, y)):
+                    wgrad(d, g, dw, db)
         return dx, dw, db, (g if has_res else None), dslope, None, None, None, None
 
 

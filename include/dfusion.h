@@ -224,10 +224,14 @@ int df_conv3x3_winograd_nhwc(const df_conv_desc *d, void *scratch, size_t scratc
  *          read that input pixel; runs on the same MFMA kernel as the forward pass on flipped, transposed weights
  *          (w_scratch: Cout*KH*KW*Cin floats) with input dilation = the forward stride.  accumulate != 0 adds into dx.
  *   wgrad: dw[n][ky][kx][c] = sum_pixels dy[.][n] * x[. shifted by tap][c];  db[n] = sum_pixels dy[.][n] (db may be NULL).
+ *          The pixel range is split over workgroups; their partial tiles go through `ws` (df_conv2d_wgrad_workspace_bytes)
+ *          and are added in a fixed order, so gradients are bit-reproducible run to run (no atomics).
  * dy has the geometry of the forward output (out_ld / out_coff of `d`); activation masks are the caller's business. */
 int df_conv2d_dgrad_nhwc(const df_conv_desc *d, const float *dy, float *dx, float *w_scratch, int accumulate,
                          df_stream_t stream);
-int df_conv2d_wgrad_nhwc(const df_conv_desc *d, const float *dy, float *dw, float *db, df_stream_t stream);
+size_t df_conv2d_wgrad_workspace_bytes(const df_conv_desc *d);
+int df_conv2d_wgrad_nhwc(const df_conv_desc *d, const float *dy, float *dw, float *db, void *ws, size_t ws_bytes,
+                         df_stream_t stream);
 
 /* Per-launch timing of the GEMM kernel with HIP events on the call's stream (bench.py roofline).
  * df_net_profile(net, 1) arms it; after the stream has been synchronised df_net_profile_read returns the

@@ -185,3 +185,66 @@ def test_training_gradients_match_the_references_backward():
     for k in keys:
         got = torch.from_numpy(grad_sample(params[k].grad.cpu().numpy()))
         _close(got, torch.from_numpy(g["grad:" + k]), 2e-3, k)
+
+
+def test_training_step_gradients_at_the_ycb_training_shape():
+    """BASELINE configs[3] at its real sizes: K = 21 objects, N = 1000 points, M = 500 mesh points, a SYMMETRIC object (the
+    250 M-pair 1-NN loss branch), one 80 x 120 frame -- loss and all parameter gradients against torch CPU autograd through
+    the oracle restatement."""
+    from densefusion_amd.lib import train_graph
+    from densefusion_amd.lib.loss import Loss
+    from densefusion_amd.lib.network import PoseNet
+    K, N, H, W, M = 21, 1000, 80, 120, 500
+    sym_list = [12, 15, 18, 19, 20]
+    sd = synth.make_state_dict(synth.posenet_spec(K), 13)
+    o = synth.make_object(105, H, W, N, K, num_points_mesh=M)
+    idx = torch.tensor([[15]])
+    T = lambda k: torch.from_numpy(o[k])[None]
+    psd = {k: torch.from_numpy(v).clone().requires_grad_() for k, v in sd.items()}
+    r, t, c, emb = dfnet.posenet_forward(psd, T("img"), T("cloud"), torch.from_numpy(o["choose"]), idx)
+    want_loss = loss_ref.loss_calculation(r, t, c, T("target"), T("model_points"), idx, T("cloud"), 0.015, False, M, sym_list)[0]
+    want_loss.backward()
+    net = PoseNet(N, K)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.cuda().train()
+    gr, gt, gc, gemb = train_graph.posenet_forward(net, T("img").cuda(), T("cloud").cuda(), torch.from_numpy(o["choose"]).cuda(),
+                                                   idx.cuda(), dropout=False)
+    loss = Loss(M, sym_list)(gr, gt, gc, T("target").cuda(), T("model_points").cuda(), idx.cuda(), T("cloud").cuda(), 0.015, False)[0]
+    _close(loss, want_loss, 1e-4, "loss")
+    loss.backward()
+    checked = 0
+    for key, p in net.named_parameters():
+        want = psd[key].grad
+        if "classifier" in key or want is None:
+            continue
+        if key.startswith("conv4_"):
+            # only the selected object's rows get a gradient; compare those (the others are exactly zero on both sides)
+            assert float(p.grad.abs().sum()) > 0
+        _close(p.grad, want, 3e-3, key)
+        checked += 1
+    assert checked >= 60
+
+
+def test_weight_gradients_are_bit_reproducible():
+    """Split-pixel weight gradients go through a fixed-order two-pass reduction (no atomics): the same step twice gives the
+    same bits, for the 128x128-tile kernel (Cout, K >= 128) and the 64x64 fallback."""
+    from densefusion_amd.ops import ConvNHWC
+    torch.manual_seed(3)
+    for (B, H, W, Cin, Cout, k, pad) in [(2, 40, 60, 128, 256, 3, 1), (1, 30, 40, 512, 1024, 1, 0), (2, 80, 80, 64, 64, 3, 1), (3, 50, 50, 4, 64, 7, 3)]:
+        x = torch.randn(B, H, W, Cin, device="cuda", requires_grad=True)
+        w = (torch.randn(Cout, k, k, Cin, device="cuda") * 0.05).requires_grad_()
+        b = torch.randn(Cout, device="cuda", requires_grad=True)
+        got = []
+        for _ in range(2):
+            for v in (x, w, b):
+                v.grad = None
+            y = ConvNHWC.apply(x, w, b, 1, pad, 1)
+            (y * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
+            got.append((w.grad.clone(), b.grad.clone()))
+        assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1]), (Cin, Cout, k)
+        # and against torch's own convolution gradients
+        xr, wr, br = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+        yr = torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr.permute(0, 3, 1, 2), br, padding=pad).permute(0, 2, 3, 1)
+        (yr * torch.linspace(-1, 1, yr.numel(), device="cuda").view_as(yr)).sum().backward()
+        # (db sums ~10^4 values of both signs in fp32 on both sides: cancellation leaves ~1e-4 of absolute noise)
+        _close(got[0][0], wr.grad.cpu(), 2e-4, "dw"); _close(got[0][1], br.grad.cpu(), 1e-3, "db")
