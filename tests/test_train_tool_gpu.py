@@ -85,3 +85,46 @@ def test_train_on_fabricated_linemod_tree_with_builtin_loader(tmp_path, caplog):
     assert any("built-in loader" in ln for ln in lines)
     assert sum(ln.startswith("Train time") for ln in lines) >= 10 and 1e-4 < best < 10
     assert glob.glob(str(tmp_path / "models" / "pose_model_1_*.pth"))
+
+
+def test_resumed_refiner_run_is_the_refiner_phase_from_the_start(tmp_path, monkeypatch, caplog):
+    """--resume_refinenet (tools/train.py:86-100 of the reference): refine_start is set BEFORE the datasets are built (YCB
+    then samples 2600 mesh points), and the lr / w decay is not applied a second time."""
+    import logging
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import train
+    from densefusion_amd import synth
+    common = ["--dataset", "synthetic", "--num_objects", "2", "--num_points", "64", "--synthetic_train_frames", "8",
+              "--synthetic_test_frames", "2", "--batch_size", "4", "--outf", str(tmp_path / "models"), "--log_dir", str(tmp_path / "logs")]
+    train.SyntheticPoseDataset.CROPS = [(40, 40)]
+    os.makedirs(tmp_path / "models", exist_ok=True)
+    torch.save({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.posenet_spec(2), 5).items()}, tmp_path / "models" / "p.pth")
+    torch.save({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.refiner_spec(2), 6).items()}, tmp_path / "models" / "r.pth")
+    seen = []
+    orig = train.make_datasets
+    monkeypatch.setattr(train, "make_datasets", lambda opt: (seen.append((opt.refine_start, opt.batch_size)), orig(opt))[1])
+    with caplog.at_level(logging.INFO, logger="train"):
+        train.main(common + ["--nepoch", "3", "--resume_posenet", "p.pth", "--resume_refinenet", "r.pth", "--decay_margin", "1e9",
+                             "--refine_margin", "1e9"])
+    assert seen and seen[0] == (True, 2)                      # refiner phase (and batch_size / iteration) known when the datasets are built
+    assert not [r for r in caplog.records if r.getMessage().startswith("decay:")]       # already decayed: never again
+
+
+def test_two_rank_trainer_with_a_dataset_that_does_not_divide(tmp_path):
+    """Two data-parallel ranks (gloo, both on the one card) over 15 frames with 4 frames per optimizer step: the shards come
+    from one shared permutation and every rank takes the same number of steps, so no rank is left waiting in the gradient
+    all-reduce (the run finishes) and both log the same number of optimizer steps."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, DF_TRAIN_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "train.py"), "--dist_backend", "gloo", "--dataset", "synthetic",
+           "--num_objects", "2", "--num_points", "64", "--synthetic_train_frames", "15", "--synthetic_test_frames", "3", "--batch_size", "4",
+           "--nepoch", "3", "--refine_margin", "-1", "--decay_margin", "-1", "--outf", str(tmp_path / "models"), "--log_dir", str(tmp_path / "logs")]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
+    assert out.returncode == 0, out.stdout[-3000:]
+    # rank 0 logs at INFO: 15 // (2 * 4) = 1 optimizer step per epoch, two epochs
+    assert out.stdout.count("Train time") == 2 and out.stdout.count("TEST FINISH") == 2, out.stdout[-3000:]

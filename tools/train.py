@@ -90,6 +90,9 @@ def build_parser():
     ap.add_argument("--synthetic_train_frames", type=int, default=64)
     ap.add_argument("--synthetic_test_frames", type=int, default=16)
     ap.add_argument("--refine_start", action="store_true")
+    ap.add_argument("--seed", type=int, default=1000, help="base seed; the epoch permutation uses seed + epoch on EVERY rank")
+    ap.add_argument("--dist_backend", type=str, default="nccl", help="torch.distributed backend under torch.distributed.run "
+                                                                     "(nccl = RCCL over xGMI; gloo to rehearse several ranks on one GPU)")
     return ap
 
 
@@ -124,28 +127,45 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        if opt.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(opt.dist_backend, rank=rank, world_size=world)
+    if "DF_TRAIN_DEVICE" in os.environ:            # rehearsal only: several ranks sharing one card
+        local = int(os.environ["DF_TRAIN_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    torch.manual_seed(1000 + rank)
-    np.random.seed(1000 + rank)
+    torch.manual_seed(opt.seed + rank)             # dropout masks / initial weights may differ per rank; the data order may not
+    np.random.seed(opt.seed + rank)
     logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format="%(message)s")
     log = logging.getLogger("train")
     os.makedirs(opt.outf, exist_ok=True)
     os.makedirs(opt.log_dir, exist_ok=True)
 
+    decay_start = False
+    if opt.resume_refinenet:
+        # a resumed refiner run IS the refiner phase (tools/train.py:86-100): set it BEFORE the datasets are built (YCB
+        # samples 2600 mesh points instead of 500 when refine = True, datasets/ycb/dataset.py:90-91,240-244), and the
+        # learning-rate / w decay has already been applied -- it must not be applied a second time
+        opt.refine_start = True
+        decay_start = True
+        opt.lr *= opt.lr_rate
+        opt.w *= opt.w_rate
+        opt.batch_size = max(1, int(opt.batch_size / opt.iteration))
     dataset, test_dataset = make_datasets(opt)
     estimator = PoseNet(num_points=opt.num_points, num_obj=opt.num_objects).to(dev)
     refiner = PoseRefineNet(num_points=opt.num_points, num_obj=opt.num_objects).to(dev)
+    if world > 1 and not opt.resume_posenet:
+        # data-parallel replicas must start from the same weights: rank 0's initialisation goes to everybody
+        for prm in list(estimator.parameters()) + list(refiner.parameters()):
+            buf = prm.data if opt.dist_backend == "nccl" else prm.data.cpu()
+            dist.broadcast(buf, 0)
+            if opt.dist_backend != "nccl":
+                prm.data.copy_(buf)
     if opt.resume_posenet:
         estimator.load_state_dict(torch.load(os.path.join(opt.outf, opt.resume_posenet), map_location=dev, weights_only=True))
     if opt.resume_refinenet:
         refiner.load_state_dict(torch.load(os.path.join(opt.outf, opt.resume_refinenet), map_location=dev, weights_only=True))
-        opt.refine_start = True
-        opt.lr *= opt.lr_rate
-        opt.w *= opt.w_rate
-        opt.batch_size = max(1, int(opt.batch_size / opt.iteration))
-    decay_start = False
 
     def optimizer_for(module):
         flat = train_utils.FlatParams(module)
@@ -158,6 +178,14 @@ def main(argv=None):
     criterion_refine = Loss_refine(opt.num_points_mesh, opt.sym_list)
     log.info(">>>>>>>>----------Dataset loaded!---------<<<<<<<<\nlength of the training set: %d\nlength of the testing set: %d\n"
              "number of sample points on mesh: %d\nsymmetry object list: %s", len(dataset), len(test_dataset), opt.num_points_mesh, opt.sym_list)
+
+    def allreduce(fl):
+        if world > 1 and opt.dist_backend != "nccl":              # gloo rehearsal: through host memory
+            g = fl.grad.cpu()
+            dist.all_reduce(g)
+            fl.grad.copy_(g)
+            return world
+        return train_utils.allreduce_gradients(fl)
 
     def to_dev(data):
         points, choose, img, target, model_points, idx = data
@@ -206,15 +234,22 @@ def main(argv=None):
             estimator.train()
         flat.zero_grad()
         train_count, train_dis_avg = 0, 0.0
-        order = np.random.permutation(len(dataset))[rank::world]       # this rank's shard of the epoch
-        window = []
+        # this rank's shard of the epoch.  The permutation comes from a seed EVERY rank shares (seed + epoch), so the shards are
+        # disjoint; all ranks take the same number of frames and therefore the same number of optimizer steps -- the gradient
+        # all-reduce is a collective, a rank that ran one step fewer would leave the others waiting in it.  Lost-detection
+        # sentinels (LineMOD) count toward the window like any frame: they add no gradient but never skip a collective.
+        perm = np.random.RandomState(opt.seed + epoch).permutation(len(dataset))
+        steps = len(dataset) // (world * opt.batch_size)
+        order = perm[:steps * world * opt.batch_size][rank::world]
+        window, slots = [], 0
         for i in order:
             data = to_dev(dataset[int(i)])
-            if data is None:
+            slots += 1
+            if data is not None:
+                window.append(data)
+            if slots < opt.batch_size:
                 continue
-            window.append(data)
-            if len(window) < opt.batch_size:
-                continue
+            slots = 0
             # one accumulation window = one optimizer step (tools/train.py:131-170); frames of equal crop size may share
             # a pass (--frames_per_pass): the summed gradient of the window does not depend on how it is cut into passes
             by_size = {}
@@ -228,7 +263,7 @@ def main(argv=None):
             prev = train_count
             train_count += opt.batch_size
             frames_seen += opt.batch_size
-            n = train_utils.allreduce_gradients(flat)             # the one collective of the training path
+            n = allreduce(flat)                                   # the one collective of the training path
             optimizer.step(grad_scale=1.0 / n)
             flat.zero_grad()
             log.info("Train time %s Epoch %d Batch %d Frame %d Avg_dis:%f", time.strftime("%Hh %Mm %Ss", time.gmtime(time.time() - st_time)),
@@ -258,7 +293,7 @@ def main(argv=None):
                         dis, new_points, new_target = criterion_refine(pred_r, pred_t, new_target, model_points, idx, new_points)
                 test_dis += float(dis)
                 test_count += 1
-        stats = torch.tensor([test_dis, float(test_count)], device=dev, dtype=torch.float64)
+        stats = torch.tensor([test_dis, float(test_count)], device=dev if opt.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         if world > 1:
             dist.all_reduce(stats)
         test_dis = float(stats[0] / max(stats[1], 1.0))
@@ -276,6 +311,7 @@ def main(argv=None):
             opt.lr *= opt.lr_rate
             opt.w *= opt.w_rate
             optimizer = train_utils.FlatAdam(flat, lr=opt.lr)
+            log.info("decay: lr -> %g, w -> %g", opt.lr, opt.w)
         if best_test < opt.refine_margin and not opt.refine_start:
             opt.refine_start = True
             opt.batch_size = max(1, int(opt.batch_size / opt.iteration))
