@@ -45,6 +45,7 @@ struct Net {
   std::vector<std::string> ev_desc;
   size_t ev_used = 0;
   // debug taps (df_net_debug_taps): copies of named intermediates of the last single-bucket forward, channels-last
+  bool psp_dirty = false;               // a psp.* weight changed since the folded matrices were built
   bool taps_on = false;
   struct Tap { float *buf = nullptr; size_t cap = 0; int64_t shape[4] = {0, 0, 0, 0}; };
   std::map<std::string, Tap> taps;
@@ -269,29 +270,32 @@ static int load_param(Net &n, const std::string &key, const float *src, int64_t 
   }
   if (e != hipSuccess) return set_error(DF_ERR_LAUNCH, "load_param(%s): %s", key.c_str(), hipGetErrorString(e));
   n.loaded[it->second] = 1;
-  if (n.kind == 0 && key.find(".psp.") != std::string::npos && !ends_with(key, ".bias")) {
-    // (re)build the folded PSP weights once the bottleneck and all four stage weights are present
-    const std::string P = CNN;
-    bool all = n.loaded[n.index[P + "psp.bottleneck.weight"]];
-    for (int st = 0; st < 4; ++st) all = all && n.loaded[n.index[P + "psp.stages." + std::to_string(st) + ".1.weight"]];
-    if (all) {
-      float *wc = dev_alloc(n, "psp.fold.w", (size_t)4 * 1024 * 512), *wf = dev_alloc(n, "psp.fold.wfeat", (size_t)1024 * 512);
-      if (!wc || !wf) return set_error(DF_ERR_LAUNCH, "psp fold: hipMalloc failed");
-      const float *wb = n.buf[P + "psp.bottleneck.weight"];
-      hipMemcpy2D(wf, 512 * sizeof(float), wb + 2048, 2560 * sizeof(float), 512 * sizeof(float), 1024, hipMemcpyDeviceToDevice);
-      for (int st = 0; st < 4; ++st)
-        hipLaunchKernelGGL(psp_fold_kernel, dim3(2, 1024, 1), dim3(256), 0, 0, wb, n.buf[P + "psp.stages." + std::to_string(st) + ".1.weight"], wc, st);
-      hipDeviceSynchronize();
-      if (check_launch("psp fold") != DF_OK) return DF_ERR_LAUNCH;
-    }
-  }
+  // the folded PSP matrices depend on five tensors: rebuilt once, by the next forward call (ensure_derived), not per key
+  if (n.kind == 0 && key.find(".psp.") != std::string::npos && !ends_with(key, ".bias")) n.psp_dirty = true;
   return DF_OK;
 }
 
-static int check_ready(const Net &n) {
+// (re)build what is derived from several parameters: the PSP fold (bottleneck x stage weights, fp64 accumulation)
+static int ensure_derived(Net &n) {
+  if (!n.psp_dirty) return DF_OK;
+  const std::string P = CNN;
+  float *wc = dev_alloc(n, "psp.fold.w", (size_t)4 * 1024 * 512), *wf = dev_alloc(n, "psp.fold.wfeat", (size_t)1024 * 512);
+  if (!wc || !wf) return set_error(DF_ERR_LAUNCH, "psp fold: hipMalloc failed");
+  const float *wb = n.buf[P + "psp.bottleneck.weight"];
+  hipMemcpy2D(wf, 512 * sizeof(float), wb + 2048, 2560 * sizeof(float), 512 * sizeof(float), 1024, hipMemcpyDeviceToDevice);
+  for (int st = 0; st < 4; ++st)
+    hipLaunchKernelGGL(psp_fold_kernel, dim3(2, 1024, 1), dim3(256), 0, 0, wb, n.buf[P + "psp.stages." + std::to_string(st) + ".1.weight"], wc, st);
+  hipDeviceSynchronize();
+  if (check_launch("psp fold") != DF_OK) return DF_ERR_LAUNCH;
+  n.psp_dirty = false;
+  return DF_OK;
+}
+
+static int check_ready(const Net &n0) {
+  Net &n = const_cast<Net &>(n0);
   for (size_t i = 0; i < n.spec.size(); ++i)
     if (!n.loaded[i]) return set_error(DF_ERR_STATE, "parameter '%s' was never loaded", n.spec[i].key.c_str());
-  return DF_OK;
+  return ensure_derived(n);
 }
 
 // ------------------------------------------------------------------------------------------------

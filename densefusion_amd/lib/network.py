@@ -73,11 +73,17 @@ class _EngineModule(nn.Module):
                 _lib.check(-1, "create")
             self._handle_dev = device
             self._uploaded = {}
+        synced = False
         for key, p in self.named_parameters():
             if p.device != device:
                 raise RuntimeError(f"parameter {key} is on {p.device}, input on {device}: call .cuda() first")
             tag = (p.data_ptr(), p._version)
             if self._uploaded.get(key) != tag:
+                if not synced:
+                    # df_net_load_param copies with blocking calls outside torch's streams: an optimizer update still in
+                    # flight on the current stream must have landed before the parameters are read
+                    torch.cuda.current_stream(device).synchronize()
+                    synced = True
                 src = p.detach()
                 if src.dtype != torch.float32 or not src.is_contiguous():
                     src = src.float().contiguous()

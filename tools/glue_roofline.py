@@ -1,0 +1,87 @@
+"""Dev tool: achieved HBM GB/s of the memory-bound glue kernels of one bench step against their algorithmic bytes.
+
+    python tools/glue_roofline.py KERNEL_STATS.csv PASSES OUT.json
+
+KERNEL_STATS.csv: `rocprofv3 --kernel-trace --stats` of a SERIAL bench run (tools/dev/prof_serial.sh: one stream, no graph,
+--groups 1), PASSES = number of passes over the step's 280 objects in that run (eager + warm-up + timed + profiled steps).
+Algorithmic bytes (every tensor a kernel must read / write, once, fp32) are computed here from the bench workload: K = 21,
+N = 1000 (Npad = 1024), 40 objects of each of the seven crop sizes, 2 refine iterations."""
+import csv
+import json
+import sys
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import bench  # noqa: E402
+
+HBM = bench.HBM_PEAK_GBS
+N, NPAD, PER, ITERS = bench.N_PTS, 1024, 40, bench.ITERS
+
+
+def wino_geom(H, W, d):
+    TH, TW = ((H + d - 1) // d + 1) // 2, ((W + d - 1) // d + 1) // 2
+    return d * d * TH * TW
+
+
+def wino_pays(H, W, d, cin):
+    return cin >= 256 and 16.0 * wino_geom(H, W, d) <= 0.72 * 9.0 * H * W
+
+
+def step_bytes():
+    b = {}
+    add = lambda k, v: b.__setitem__(k, b.get(k, 0.0) + v)
+    for (H, W) in bench.CROPS:
+        B = PER
+        h2, w2 = H // 2, W // 2            # stem
+        h4, w4 = H // 4, W // 4            # pool / layer1
+        h, w = H // 8, W // 8              # layer2..4, psp
+        add("nchw3_to_nhwc4_kernel", B * (3 + 4) * H * W * 4)
+        add("maxpool3s2_kernel", B * (h2 * w2 + h4 * w4) * 64 * 4)
+        # Winograd-domain convs (engine.hip cnn_forward): (cin, cout, dil, residual)
+        for cin, cout, d, res in ((256, 256, 1, True), (256, 256, 2, False), (256, 256, 2, True), (256, 512, 1, False), (512, 512, 1, True),
+                                  (512, 512, 4, False), (512, 512, 4, True)):
+            if not wino_pays(h, w, d, cin):
+                continue
+            T = wino_geom(h, w, d)
+            add("wino_input_kernel", B * (h * w * cin + 16 * T * cin) * 4)
+            add("wino_output_kernel", B * (16 * T * cout + h * w * cout * (2 if res else 1)) * 4)
+        add("psp_pool_kernel", B * (h * w * 512 + 50 * 512) * 4)
+        add("psp_prior_sum_kernel", B * (50 * 1024 + h * w * 1024) * 4)
+        add("upconv_gather_tiled_kernel", B * (h * w * 9 * 256 + 4 * h * w * 256) * 4)          # up_1
+        add("upconv_gather_tiled_kernel", B * (4 * h * w * 9 * 64 + 16 * h * w * 64) * 4)        # up_2
+        add("up3_patch_kernel", B * (min(16 * h * w * 64, N * 36 * 64) + NPAD * 576) * 4)
+    Bt = PER * len(bench.CROPS)
+    add("final_lsm_kernel", Bt * (NPAD * 64 + 2 * N * 32) * 4)
+    add("cloud_conv1_kernel", (1 + ITERS) * Bt * (N * 3 + NPAD * 64) * 4)
+    add("fc_rows_kernel", (1920 * 1024 + Bt * (1024 + 1920)) * 4)                                      # global-feature half of head layer 1
+    add("fc_rows_kernel", ITERS * ((1024 * 1024 + Bt * 2048) + (2 * 128 * 512 + Bt * (1024 + 256))) * 4)   # refiner FC towers
+    add("head_conf_kernel", Bt * (NPAD * 128 + N) * 4)
+    add("head_select_kernel", (Bt * (N + 384 + 1920) + 1280 * 384 + 2 * 256 * 640 + 2 * 128 * 256) * 4)
+    add("colsum_finish_kernel", (1 + ITERS) * Bt * (16 * 1024 + 1024) * 4)
+    return b
+
+
+def main():
+    path, passes, out = sys.argv[1], float(sys.argv[2]), sys.argv[3]
+    alg = step_bytes()
+    rows = []
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            for k in alg:
+                if k in r["Name"]:
+                    us = int(r["TotalDurationNs"]) / passes / 1e3
+                    gbs = alg[k] / us / 1e3
+                    rows.append({"kernel": k, "calls_per_step": round(int(r["Calls"]) / passes, 1), "us_per_step": round(us, 1),
+                                 "algorithmic_mb_per_step": round(alg[k] / 1e6, 1), "achieved_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM, 3)})
+    rows.sort(key=lambda r: -r["us_per_step"])
+    res = {"workload": "bench.py step: 280 objects (40 of each of 7 crop sizes), N=1000, 2 refine iterations; serial run (one stream, no graph, --groups 1)",
+           "hbm_peak_GBps": HBM, "source_csv": path, "passes": passes, "kernels": rows,
+           "glue_us_per_step": round(sum(r["us_per_step"] for r in rows), 1)}
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    for r in rows:
+        print(f"{r['kernel']:30s} {r['us_per_step']:8.1f} us  {r['algorithmic_mb_per_step']:9.1f} MB  {r['achieved_GBps']:7.1f} GB/s  {r['hbm_frac']:.3f}")
+    print("glue total", res["glue_us_per_step"], "us / step")
+
+
+if __name__ == "__main__":
+    main()
