@@ -269,7 +269,7 @@ def bench_loss():
             "fp32_valu_frac": round(9.0 * N * M * M / us / 1e6 / FP32_PEAK_TFLOPS, 4)}
 
 
-def bench_entry_point(est, ref, device, windows=6, frames=56):
+def bench_entry_point(est, ref, device, windows=9, frames=56):
     """The kept entry point's device pipeline (tools/eval_ycb.py -> densefusion_amd.lib.eval_window.WindowEstimator) on
     synthetic YCB-shaped frames that start in PINNED HOST memory: per window of `frames` keyframes (5 detections each, boxes
     cycling over the bench's seven crop sizes) one upload on a copy stream, device-side input preparation per crop-size
@@ -297,23 +297,25 @@ def bench_entry_point(est, ref, device, windows=6, frames=56):
             dets.append((f, itemid, roi, 1000 + k))
             k += 1
     label = torch.from_numpy(label_np).pin_memory()
-    we = WindowEstimator(est, ref, N_PTS, ITERS, frames, (IH, IW))
-    pending = we.submit(rgb, depth, label, dets)
-    WindowEstimator.collect(pending)                      # warm-up: workspace sizing
+    from collections import deque
+    depth_ = 3
+    we = WindowEstimator(est, ref, N_PTS, ITERS, frames, (IH, IW), depth=depth_)
+    for _ in range(depth_ + 1):                           # warm-up: every slot's workspace sized
+        WindowEstimator.collect(we.submit(rgb, depth, label, dets))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pending, lost = None, 0
+    pending, lost = deque(), 0
     for _ in range(windows):
-        h = we.submit(rgb, depth, label, dets)
-        if pending is not None:
-            lost += int(WindowEstimator.collect(pending)[2].sum())
-        pending = h
-    lost += int(WindowEstimator.collect(pending)[2].sum())
+        while len(pending) >= depth_:
+            lost += int(WindowEstimator.collect(pending.popleft())[2].sum())
+        pending.append(we.submit(rgb, depth, label, dets))
+    while pending:
+        lost += int(WindowEstimator.collect(pending.popleft())[2].sum())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = len(dets) * windows
     return {"entry_point_poses_per_s": round((n - lost) / dt, 1), "frames_per_window": frames, "detections_per_window": len(dets),
-            "windows": windows, "lost": lost, "ms_per_window": round(dt / windows * 1e3, 2),
+            "windows": windows, "windows_in_flight": depth_, "lost": lost, "ms_per_window": round(dt / windows * 1e3, 2),
             "h2d_mb_per_window": round((rgb.numel() + depth.numel() * 2 + label.numel() * 4) / 1e6, 1),
             "note": "pinned host frames -> upload (copy stream) -> device input preparation -> one multi-bucket estimate -> poses to host; "
                     "what tools/eval_ycb.py runs per --window, without PNG decoding / .mat writing"}
@@ -469,10 +471,14 @@ def main():
     ap.add_argument("--per-bucket", type=int, default=40, help="objects of each crop size per step and GPU")
     ap.add_argument("--refine-iters", type=int, default=ITERS, help="refine iterations per pose (metric: 2; BASELINE configs[2] as written: 4)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("DF_BENCH_GROUPS", "2")),
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("DF_BENCH_GROUPS", "1")),
                     help="split the step's objects into this many multi-bucket calls, one HIP stream each (0: one call per crop size, "
                          "the round-1 launch structure)")
     ap.add_argument("--no-streams", action="store_true", help="run the groups back to back on one stream")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("DF_BENCH_INFLIGHT", "3")),
+                    help="steps in flight: consecutive steps (independent batches of the frame stream) alternate between this many "
+                         "instances (own workspaces, output buffers, stream, hipGraph), so one step's memory-bound kernels overlap "
+                         "the next step's GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse "
@@ -498,56 +504,67 @@ def main():
 
     est, ref = load_nets(device)
     buckets = make_buckets(rank, world, args.per_bucket, device)
-    groups = make_groups(buckets, args.groups, device)
-    pe = [PoseEstimator(est, ref) for _ in groups]          # one workspace per group (they may run concurrently)
-    streams = None if (args.no_streams or len(groups) == 1) else [torch.cuda.Stream() for _ in groups]
     poses_per_step = args.per_bucket * len(CROPS)
     gdev = device if args.backend == "nccl" else torch.device("cpu")
     gathered = [torch.empty(poses_per_step, 7, dtype=torch.float64, device=gdev) for _ in range(world)] if world > 1 else None
 
-    def gather():      # results to every rank: the only communication of the inference path (a few KB per step)
-        mine = torch.cat([g["out"][1] for g in groups])
-        dist.all_gather(gathered, mine if args.backend == "nccl" else mine.cpu())
+    class Instance:
+        """One step in flight: its own group workspaces, output buffers, stream and (captured) hipGraph; the inputs are shared."""
 
-    def step():
-        run_step(pe, groups, streams)
-        if world > 1:
-            gather()
-
-    run_step(pe, groups)                       # eager pass: uploads weights, sizes the workspace
-    torch.cuda.synchronize()
-    graph = None
-    if not args.no_graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                run_step(pe, groups, streams)
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime
-                run_step(pe, groups, streams)
-        except Exception as e:                 # noqa: BLE001
-            print(f"[bench] hipGraph capture failed ({e}); running eagerly", file=sys.stderr)
-            graph = None
+        def __init__(self):
+            self.groups = make_groups(buckets, args.groups, device)
+            self.pe = [PoseEstimator(est, ref) for _ in self.groups]          # one workspace per group (they may run concurrently)
+            self.gstreams = None if (args.no_streams or len(self.groups) == 1) else [torch.cuda.Stream() for _ in self.groups]
+            self.stream = torch.cuda.Stream()
+            self.graph = None
+            run_step(self.pe, self.groups)                                     # eager pass: uploads weights, sizes the workspaces
             torch.cuda.synchronize()
+            if not args.no_graph:
+                try:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        run_step(self.pe, self.groups, self.gstreams)
+                    torch.cuda.current_stream().wait_stream(side)
+                    self.graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime
+                        run_step(self.pe, self.groups, self.gstreams)
+                except Exception as e:                 # noqa: BLE001
+                    print(f"[bench] hipGraph capture failed ({e}); running eagerly", file=sys.stderr)
+                    self.graph = None
+                    torch.cuda.synchronize()
 
-    def timed_step():
-        if graph is not None:
-            graph.replay()
-            if world > 1:
-                gather()
-        else:
-            step()
+        def launch(self):
+            """enqueue one step on this instance's stream (no host sync)"""
+            with torch.cuda.stream(self.stream):
+                if self.graph is not None:
+                    self.graph.replay()
+                else:
+                    run_step(self.pe, self.groups, self.gstreams)
 
-    for _ in range(args.warmup):
-        timed_step()
+        def gather(self):      # results to every rank: the only communication of the inference path (a few KB per step)
+            torch.cuda.current_stream().wait_stream(self.stream)
+            mine = torch.cat([g["out"][1] for g in self.groups])
+            dist.all_gather(gathered, mine if args.backend == "nccl" else mine.cpu())
+
+    insts = [Instance() for _ in range(max(1, args.inflight))]
+    groups, pe = insts[0].groups, insts[0].pe
+    graph, streams = insts[0].graph, insts[0].gstreams
+
+    def timed_step(i):
+        inst = insts[i % len(insts)]
+        inst.launch()
+        if world > 1:
+            inst.gather()
+
+    for i in range(args.warmup):
+        timed_step(i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        timed_step()
+    for i in range(args.steps):
+        timed_step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -569,7 +586,7 @@ def main():
                                    "K=21 objects, N=1000 points, crops cycled over 80x80..240x320, 5 objects/frame)",
                        "num_obj": K_OBJ, "num_points": N_PTS, "refine_iters": ITERS, "crops": CROPS,
                        "objects_per_step_per_gpu": poses_per_step, "frames_per_step_per_gpu": poses_per_step / 5,
-                       "hipgraph": graph is not None, "groups": len(groups), "group_streams": streams is not None, "sharding": f"objects round-robin over {world} rank(s), no data-path collective",
+                       "hipgraph": graph is not None, "groups": len(groups), "group_streams": streams is not None, "steps_in_flight": len(insts), "sharding": f"objects round-robin over {world} rank(s), no data-path collective",
                        "reference_algorithm_gflop_per_step_per_gpu": round(gflop_step, 1),
                        "note": "reference_algorithm_* counts the FLOPs of the reference's own layer graph (SURVEY 8d); this build "
                                "executes fewer (PSP fold, low-resolution up-convs, Winograd-domain trunk, chosen-pixel up_3, confidence-first heads: DESIGN.md 5), so that rate may exceed the fp32 peak"},

@@ -10,7 +10,9 @@ device->host sync, ``iteration`` refiner round trips).  ``WindowEstimator`` take
     bucket's inputs are prepared on the device in one launch (``preprocess_objects``);
   * all buckets go through PoseNet -> pose selection -> refine loop as ONE device call (``df_estimate_poses_multi``):
     every launch that does not depend on the crop size covers the whole window;
-  * one device->host copy returns the [n,7] poses of the window.
+  * one device->host copy returns the [n,7] poses of the window;
+  * up to ``depth`` windows are in flight, each on its own stream with its own workspace, so one window's memory-bound
+    kernels (transforms, interpolation, input preparation) overlap the next window's GEMMs.
 
 Results per detection are bit-identical to the per-frame path (same per-object seeds, batch-size-independent kernels), so
 the ``.mat`` files tools/eval_ycb.py writes do not depend on the window length.
@@ -25,17 +27,20 @@ from .network import PoseEstimator
 
 
 class WindowEstimator:
-    def __init__(self, estimator, refiner, num_points, iteration, max_frames, frame_hw=(pp.IMG_WIDTH, pp.IMG_LENGTH), cam=pp.YCB_CAM):
-        self.pe = PoseEstimator(estimator, refiner)
+    def __init__(self, estimator, refiner, num_points, iteration, max_frames, frame_hw=(pp.IMG_WIDTH, pp.IMG_LENGTH), cam=pp.YCB_CAM,
+                 depth=3):
+        self.depth = max(1, int(depth))
         self.num_points, self.iteration, self.cam = int(num_points), int(iteration), cam
         self.dev = next(estimator.parameters()).device
         IH, IW = frame_hw
         self.max_frames = int(max_frames)
-        # two device slots: window i+1 uploads while window i computes
+        # `depth` windows in flight (callers collect window i - depth + 1 before submitting window i + 1): one device slot,
+        # compute stream and workspace each, plus one slot that may be uploading
         self.slots = [dict(rgb=torch.empty(max_frames, IH, IW, 3, dtype=torch.uint8, device=self.dev),
                            depth=torch.empty(max_frames, IH, IW, dtype=torch.int16, device=self.dev),
                            label=torch.empty(max_frames, IH, IW, dtype=torch.int32, device=self.dev),
-                           ready=torch.cuda.Event()) for _ in range(2)]
+                           ready=torch.cuda.Event(), done=torch.cuda.Event(), stream=torch.cuda.Stream(device=self.dev),
+                           pe=PoseEstimator(estimator, refiner)) for _ in range(self.depth + 1)]
         self.copy_stream = torch.cuda.Stream(device=self.dev)
         self._n = 0
 
@@ -46,9 +51,10 @@ class WindowEstimator:
         F = rgb.shape[0]
         if F > self.max_frames:
             raise RuntimeError(f"window of {F} frames exceeds max_frames={self.max_frames}")
-        slot = self.slots[self._n % 2]
+        slot = self.slots[self._n % len(self.slots)]
         self._n += 1
-        main = torch.cuda.current_stream(self.dev)
+        main = slot["stream"]
+        self.copy_stream.wait_stream(torch.cuda.current_stream(self.dev))     # whatever filled the caller's buffers
         with torch.cuda.stream(self.copy_stream):
             slot["rgb"][:F].copy_(rgb, non_blocking=True)
             slot["depth"][:F].copy_(depth.view(torch.int16) if depth.dtype != torch.int16 else depth, non_blocking=True)
@@ -65,19 +71,22 @@ class WindowEstimator:
                 lost[k] = True          # degenerate PoseCNN box: the reference ends in its "Detector Lost" branch (eval_ycb.py:234-237)
                 continue
             buckets.setdefault((H, W), []).append((k, frame, int(itemid), bb, int(seed)))
-        handle = dict(n=n, lost=lost, order=[], counts=[], out=None)
+        handle = dict(n=n, lost=lost, order=[], counts=[], out=None, done=slot["done"])
         if not buckets:
             return handle
         imgs, clouds, chooses, objs = [], [], [], []
-        for (H, W), members in sorted(buckets.items()):
-            objects = [(frame, itemid, bb, seed) for _, frame, itemid, bb, seed in members]
-            img, cloud, choose, count = pp.preprocess_objects(slot["rgb"][:F], slot["depth"][:F], slot["label"][:F], objects, self.num_points, self.cam)
-            imgs.append(img); clouds.append(cloud); chooses.append(choose.reshape(len(members), -1)); handle["counts"].append(count)
-            objs.append(torch.tensor([itemid - 1 for _, _, itemid, _, _ in members], dtype=torch.int64))
-            handle["order"] += [k for k, *_ in members]
-        obj = torch.cat(objs).pin_memory().to(self.dev, non_blocking=True)
-        handle["out"] = self.pe.estimate_multi(imgs, torch.cat(clouds), torch.cat(chooses), obj, self.iteration)
-        handle["counts"] = torch.cat(handle["counts"])
+        with torch.cuda.stream(main):
+            for (H, W), members in sorted(buckets.items()):
+                objects = [(frame, itemid, bb, seed) for _, frame, itemid, bb, seed in members]
+                img, cloud, choose, count = pp.preprocess_objects(slot["rgb"][:F], slot["depth"][:F], slot["label"][:F], objects, self.num_points, self.cam)
+                imgs.append(img); clouds.append(cloud); chooses.append(choose.reshape(len(members), -1)); handle["counts"].append(count)
+                objs.append(torch.tensor([itemid - 1 for _, _, itemid, _, _ in members], dtype=torch.int64))
+                handle["order"] += [k for k, *_ in members]
+            obj = torch.cat(objs).pin_memory().to(self.dev, non_blocking=True)
+            handle["out"] = slot["pe"].estimate_multi(imgs, torch.cat(clouds), torch.cat(chooses), obj, self.iteration)
+            handle["counts"] = torch.cat(handle["counts"])
+            handle["host"] = tuple(t.to("cpu", non_blocking=True) for t in (*handle["out"], handle["counts"]))     # pinned by torch
+            slot["done"].record(main)
         return handle
 
     @staticmethod
@@ -87,8 +96,8 @@ class WindowEstimator:
         n = handle["n"]
         wo, ref, lost = np.zeros((n, 7)), np.zeros((n, 7)), handle["lost"].copy()
         if handle["out"] is not None:
-            p_wo, p_ref = (t.cpu().numpy() for t in handle["out"])
-            counts = handle["counts"].cpu().numpy()
+            handle["done"].synchronize()
+            p_wo, p_ref, counts = (t.numpy() for t in handle["host"])
             for j, k in enumerate(handle["order"]):
                 if counts[j] == 0:
                     lost[k] = True

@@ -60,6 +60,7 @@ def build_parser():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--window", type=int, default=32, help="keyframes per device call (1 = frame by frame)")
     ap.add_argument("--workers", type=int, default=8, help="PNG / .mat reader threads")
+    ap.add_argument("--depth", type=int, default=3, help="windows in flight on the device (own stream and workspace each)")
     return ap
 
 
@@ -91,11 +92,13 @@ def main(argv=None):
     if not windows:
         return
     IH, IW = 480, 640
-    we = WindowEstimator(estimator, refiner, opt.num_points, opt.iteration, window, (IH, IW))
-    # three pinned host slots: one being filled by the reader threads, one uploading, one whose upload may still be in flight
+    depth = max(1, opt.depth)
+    we = WindowEstimator(estimator, refiner, opt.num_points, opt.iteration, window, (IH, IW), depth=depth)
+    # pinned host slots: `depth` windows whose uploads may still be in flight + the one the reader threads are filling
+    NH = depth + 2
     host = [dict(rgb=torch.empty(window, IH, IW, 3, dtype=torch.uint8).pin_memory(),
                  depth=torch.empty(window, IH, IW, dtype=torch.int16).pin_memory(),
-                 label=torch.empty(window, IH, IW, dtype=torch.int32).pin_memory()) for _ in range(3)]
+                 label=torch.empty(window, IH, IW, dtype=torch.int32).pin_memory()) for _ in range(NH)]
     pool = ThreadPoolExecutor(max_workers=max(1, opt.workers))
 
     def read_frame(slot, f, now):
@@ -108,7 +111,7 @@ def main(argv=None):
         return np.array(meta["rois"])
 
     def start_read(wi):
-        return [pool.submit(read_frame, wi % 3, f, now) for f, now in enumerate(windows[wi])]
+        return [pool.submit(read_frame, wi % NH, f, now) for f, now in enumerate(windows[wi])]
 
     def finish(wi, handle, rois_per_frame):
         wo, refined, lost = we.collect(handle)
@@ -123,21 +126,23 @@ def main(argv=None):
             print("Finish No.{0} keyframe".format(now))
             k += n
 
+    from collections import deque
     reads = {0: start_read(0)}
-    pending = None
+    pending = deque()
     for wi in range(len(windows)):
         rois_per_frame = [f.result() for f in reads.pop(wi)]
+        while len(pending) >= depth:
+            finish(*pending.popleft())                   # oldest window's results (frees its host slot), others keep running
         if wi + 1 < len(windows):
             reads[wi + 1] = start_read(wi + 1)            # decoded while this window uploads and computes
         F = len(windows[wi])
-        h = host[wi % 3]
+        h = host[wi % NH]
         dets = [(f, int(rois[idx][1]), rois[idx], opt.seed + now * 64 + idx)
                 for f, (now, rois) in enumerate(zip(windows[wi], rois_per_frame)) for idx in range(rois.shape[0])]
         handle = we.submit(h["rgb"][:F], h["depth"][:F], h["label"][:F], dets)       # enqueued, no host sync
-        if pending is not None:
-            finish(*pending)                             # the previous window's results, while this one runs
-        pending = (wi, handle, rois_per_frame)
-    finish(*pending)
+        pending.append((wi, handle, rois_per_frame))
+    while pending:
+        finish(*pending.popleft())
     pool.shutdown()
 
 
