@@ -149,15 +149,22 @@ def profile_gemm(pe, groups, steps):
     return tot[0], tot[1], tot[2], tot[3], tot_n
 
 
-def measured_traffic():
-    """HBM bytes per igemm launch from the committed PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE,
-    profiles/r02_igemm_traffic.json); None when the file is absent."""
+TRAFFIC_FILE = "r02_igemm_traffic.json"
+
+
+def measured_traffic(groups):
+    """HBM bytes per igemm launch from the committed PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE, separate passes over a
+    serial un-graphed run with --groups 1: tools/make_profiles.sh -> profiles/); None when the file is absent or the launch
+    structure differs from the profiled one."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_igemm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
             t = json.load(f)
-        per = t["hbm_bytes_corrected_per_dispatch"]["total"] if "hbm_bytes_corrected_per_dispatch" in t else t["avg_hbm_bytes_per_launch"]
-        return {"hbm_mb_per_launch": round(per / 1e6, 2), "source": "profiles/r02_igemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
-                "separate passes, serial un-graphed run of this workload; tools/make_profiles.sh)"}
+        if groups != 1:
+            return None
+        c = t["hbm_bytes_corrected_per_dispatch"]
+        return {"hbm_mb_per_launch": round(c["total"] / 1e6, 2), "read_mb": round(c["read"] / 1e6, 2), "write_mb": round(c["write"] / 1e6, 2),
+                "source": f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, serial un-graphed run of this "
+                          "workload with --groups 1; tools/make_profiles.sh)"}
     except Exception:   # noqa: BLE001
         return None
 
@@ -593,7 +600,9 @@ def main():
             "reference_algorithm_tflops_per_gpu": round(gflop_step * args.steps / dt / 1e3, 2),
         }
         ms, fl, useful, by, n = profile_gemm(pe, groups, min(args.steps, 5))
-        traffic = measured_traffic()
+        traffic = measured_traffic(len(groups))
+        if traffic and n:
+            traffic["ratio_to_algorithmic"] = round(traffic["hbm_mb_per_launch"] / (by / n / 1e6), 3)
         ach = fl / ms / 1e9 if ms > 0 else 0.0
         out["roofline"] = {"kernel": "igemm_f32_v2_kernel (implicit-GEMM conv / per-point / Winograd-domain GEMM, v_mfma_f32_32x32x2_f32; all launches of a step)",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_bench gpurun_out/pmc_fetch gpurun_out/pmc_write
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python3 bench.py > gpurun_out/prof_bench.log 2>&1
 echo "[profiles] kernel trace done"
-SER="--steps 2 --warmup 1 --no-cpu-baseline --no-knn --no-streams --no-graph"
+SER="--steps 2 --warmup 1 --no-cpu-baseline --no-knn --no-streams --no-graph --inflight 1 --groups 1"
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py $SER > gpurun_out/pmc_fetch.log 2>&1
 echo "[profiles] FETCH_SIZE pass done"
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py $SER > gpurun_out/pmc_write.log 2>&1
