@@ -166,3 +166,35 @@ def test_random_geometries_direct_and_winograd():
         got = ops.conv3x3_winograd_nhwc(x, w, dil=d)
         err = float((got.double() - want).abs().max()) / max(float(want.abs().max()), 1e-9)
         assert err < 1e-5, ((B, H, W, Cin, Cout, d), err)
+
+
+@pytest.mark.parametrize("geom", [(2, 40, 56, 4, 64, 7, 2, 3, 1), (2, 20, 28, 64, 128, 3, 2, 1, 1), (1, 21, 17, 64, 128, 1, 2, 0, 1),
+                                  (2, 12, 12, 128, 63, 1, 1, 0, 1), (1, 10, 14, 128, 21, 1, 1, 0, 1)])
+def test_v1_kernel_paths(geom):
+    """What the un-pipelined kernel (igemm_f32_kernel) is kept for, against torch: the data gradient of the strided
+    convolutions (stem 7x7/2, layer2's 3x3/2 and 1x1/2: the forward kernel run with input dilation `up` = stride) and output
+    widths that are not a multiple of 4 (the 63 / 21-wide last head layers of the training graph: whole launch on v1)."""
+    import ctypes
+    from densefusion_amd import _lib
+    from densefusion_amd.ops import _desc, conv2d_nhwc
+    B, H, W, Cin, Cout, k, s, p, d = geom
+    g = torch.Generator().manual_seed(sum(geom))
+    x = torch.randn(B, H, W, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).cuda()
+    if Cout % 4:
+        b = torch.randn(Cout, generator=g).cuda()
+        got = conv2d_nhwc(x, w, b, stride=s, pad=p, dil=d, act=1)
+        want = torch.relu(_ref(x.cpu(), w.cpu(), b.cpu(), s, p, d))
+        assert (got.cpu() - want).abs().max() < 2e-5
+        return
+    xr, wr = x.clone().requires_grad_(), w.clone()
+    y = torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr.permute(0, 3, 1, 2), stride=s, padding=p, dilation=d).permute(0, 2, 3, 1)
+    dy = torch.randn(y.shape, generator=g).cuda()
+    y.backward(dy)
+    x, w = x.contiguous(), w.contiguous()
+    dx = torch.empty_like(x)
+    scratch = torch.empty_like(w)
+    dsc = _desc(x, w, None, s, p, d)
+    _lib.check(_lib.lib().df_conv2d_dgrad_nhwc(ctypes.byref(dsc), dy.contiguous().data_ptr(), dx.data_ptr(), scratch.data_ptr(), 0,
+                                                _lib.current_stream()), "conv2d_dgrad")
+    assert (dx - xr.grad).abs().max() < 2e-5 * max(1.0, float(xr.grad.abs().max()))
