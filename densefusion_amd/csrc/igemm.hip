@@ -466,6 +466,7 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
   if (bias && nok) bv = *reinterpret_cast<const f32x4 *>(bias + n);
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  const int valid_rows = p.rows_per_group > 0 ? p.rows_valid - (m0 - grp * p.rows_per_group) : (1 << 30);
   // the residual rows are requested half a wave tile at a time (two trips to memory instead of one per group of rows)
   constexpr int NPS = WM / ERPP, HPS = NPS / 2;
 #pragma unroll
@@ -502,7 +503,8 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
     }
     if (ok && p.out) *reinterpret_cast<f32x4 *>(p.out + (size_t)m * p.out_ld + out_coff + n) = v;
     if (p.colsum) {
-      const bool real = ok && (p.rows_per_group <= 0 || (m % p.rows_per_group) < p.rows_valid);
+      // rows of this tile that count: a tile never straddles groups, so (m % rows_per_group) = (m0 % rows_per_group) + local row
+      const bool real = ok && wm * WM + row < valid_rows;
 #pragma unroll
       for (int e = 0; e < 4; ++e) csum[e] += real ? v[e] : 0.f;
     }

@@ -12,11 +12,11 @@ def main():
     dev = torch.device("cuda", 0)
     est, ref = bench.load_nets(dev)
     pe = [bench.PoseEstimator(est, ref)]
-    buckets = bench.make_buckets(0, 1, B, dev)
+    buckets = bench.make_groups(bench.make_buckets(0, 1, B, dev), 1, dev)
     for _ in range(3):
         bench.run_step(pe, buckets)
     torch.cuda.synchronize()
-    ms, fl, by, n = bench.profile_gemm(pe, buckets, 1)
+    ms, fl, useful, by, n = bench.profile_gemm(pe, buckets, 1)
     print(f"total gemm {ms:.3f} ms, {fl/ms/1e9:.1f} TFLOP/s, {n} launches")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
