@@ -38,33 +38,52 @@ def build_parser():
     ap.add_argument("--num_points", type=int, default=500)
     ap.add_argument("--iteration", type=int, default=4)
     ap.add_argument("--max_frames", type=int, default=0)
+    ap.add_argument("--window", type=int, default=64, help="test frames per device call (1 = frame by frame, like the reference)")
     return ap
 
 
 def evaluate(testdataset, estimator, refiner, diameter, opt, fw=None):
-    """The loop of tools/eval_linemod.py:68-139; returns (success_count, num_count) per object."""
+    """The loop of tools/eval_linemod.py:68-139; returns (success_count, num_count) per object.  Frames are taken ``--window`` at
+    a time: the crops of a window are bucketed by size and run through PoseNet -> arg-max pose -> refine loop as ONE device
+    call (``estimate_multi``), the ADD / ADD-S distances of the window as one ``add_metric`` launch; the log lines come out in
+    frame order and do not depend on the window (per-object results are bit-identical to frame-by-frame calls)."""
     num_objects = len(diameter)
     pe = PoseEstimator(estimator, refiner)
     sym_list = testdataset.get_sym_list()
     success_count, num_count = [0] * num_objects, [0] * num_objects
     say = (lambda m: (print(m), fw.write(m + "\n"))) if fw else print
     n = len(testdataset) if opt.max_frames <= 0 else min(opt.max_frames, len(testdataset))
-    for i in range(n):
-        points, choose, img, target, model_points, idx = testdataset[i]
-        if points.dim() == 1:                     # the loader's "no mask pixel" sentinel (datasets/linemod/dataset.py:135-137)
-            say("No.{0} NOT Pass! Lost detection!".format(i))
-            continue
-        dev = torch.device("cuda")
-        obj = int(idx.reshape(-1)[0])
-        _, pose = pe.estimate(img[None].to(dev), points[None].to(dev), choose.to(dev).reshape(1, 1, -1),
-                              idx.to(dev).reshape(1), opt.iteration)
-        dis = float(add_metric(pose, model_points[None].to(dev), target[None].to(dev), [1 if obj in sym_list else 0])[0])
-        if dis < diameter[obj]:
-            success_count[obj] += 1
-            say("No.{0} Pass! Distance: {1}".format(i, dis))
-        else:
-            say("No.{0} NOT Pass! Distance: {1}".format(i, dis))
-        num_count[obj] += 1
+    dev = torch.device("cuda")
+    window = max(1, getattr(opt, "window", 1))
+    for w0 in range(0, n, window):
+        items = [(i, testdataset[i]) for i in range(w0, min(n, w0 + window))]
+        live = [(i, it) for i, it in items if it[0].dim() != 1]       # others: the loader's "no mask pixel" sentinel (dataset.py:135-137)
+        dist = {}
+        if live:
+            buckets = {}
+            for k, (i, it) in enumerate(live):
+                buckets.setdefault(tuple(it[2].shape[-2:]), []).append(k)
+            order = [k for _, ks in sorted(buckets.items()) for k in ks]
+            imgs = [torch.stack([live[k][1][2] for k in ks]).to(dev) for _, ks in sorted(buckets.items())]
+            cat = lambda j: torch.stack([live[k][1][j] for k in order]).to(dev)
+            points, target, model_points = cat(0), cat(3), cat(4)
+            choose = torch.stack([live[k][1][1].reshape(-1) for k in order]).to(dev)
+            idx = torch.stack([live[k][1][5].reshape(-1)[0] for k in order]).to(dev)
+            _, pose = pe.estimate_multi(imgs, points, choose, idx, opt.iteration)
+            objs = [int(live[k][1][5].reshape(-1)[0]) for k in order]
+            dis = add_metric(pose, model_points, target, [1 if o in sym_list else 0 for o in objs]).cpu().tolist()
+            dist = {live[k][0]: (objs[j], dis[j]) for j, k in enumerate(order)}
+        for i, it in items:
+            if i not in dist:
+                say("No.{0} NOT Pass! Lost detection!".format(i))
+                continue
+            obj, d = dist[i]
+            if d < diameter[obj]:
+                success_count[obj] += 1
+                say("No.{0} Pass! Distance: {1}".format(i, d))
+            else:
+                say("No.{0} NOT Pass! Distance: {1}".format(i, d))
+            num_count[obj] += 1
     return success_count, num_count
 
 
