@@ -153,15 +153,20 @@ __global__ __launch_bounds__(512) void psp_pool_kernel(const float *__restrict__
 // weights (lib/pspnet.py:20-24; 1x1 conv and bilinear resampling are both linear and commute).
 __global__ __launch_bounds__(TPB) void psp_prior_sum_kernel(const float *__restrict__ z, float *__restrict__ out, int B,
                                                             int H, int W, int C) {
-  const int C4 = C / 4;
-  const long total = (long)B * H * W * C4;
+  // thread = (pixel, PV channel vectors CG apart, so that a wave's accesses stay contiguous): the bilinear source rows / columns /
+  // weights of the four stages are worked out once per thread and reused over its channels
+  constexpr int PV = 4;
+  const int C4 = C / 4, CG = C4 / PV;                     // C % 16 == 0 (1024 here)
+  const long total = (long)B * H * W * CG;
   for (long idx = blockIdx.x * (long)TPB + threadIdx.x; idx < total; idx += (long)gridDim.x * TPB) {
-    const int c = (int)(idx % C4);
-    long r = idx / C4;
+    const int cg = (int)(idx % CG);
+    long r = idx / CG;
     const int x = (int)(r % W); r /= W;
     const int y = (int)(r % H);
     const int b = (int)(r / H);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[PV];
+#pragma unroll
+    for (int v = 0; v < PV; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int stage = 0; stage < 4; ++stage) {
       const int s = stage == 0 ? 1 : stage == 1 ? 2 : stage == 2 ? 3 : 6;
@@ -169,14 +174,19 @@ __global__ __launch_bounds__(TPB) void psp_prior_sum_kernel(const float *__restr
       float wy0, wy1, wx0, wx1;
       src_hp(y, (float)s / (float)H, s, y0, y1, wy0, wy1);
       src_hp(x, (float)s / (float)W, s, x0, x1, wx0, wx1);
-      const f32x4 *src = reinterpret_cast<const f32x4 *>(z + ((size_t)stage * B * 36 + (size_t)b * s * s) * C);
-      const f32x4 v00 = src[(y0 * s + x0) * C4 + c], v01 = src[(y0 * s + x1) * C4 + c];
-      const f32x4 v10 = src[(y1 * s + x0) * C4 + c], v11 = src[(y1 * s + x1) * C4 + c];
-      const f32x4 v = lerp4(v00, v01, v10, v11, wy0, wy1, wx0, wx1);
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(z + ((size_t)stage * B * 36 + (size_t)b * s * s) * C) + cg;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] += v[e];
+      for (int v = 0; v < PV; ++v) {
+        const f32x4 v00 = src[(y0 * s + x0) * C4 + v * CG], v01 = src[(y0 * s + x1) * C4 + v * CG];
+        const f32x4 v10 = src[(y1 * s + x0) * C4 + v * CG], v11 = src[(y1 * s + x1) * C4 + v * CG];
+        const f32x4 t = lerp4(v00, v01, v10, v11, wy0, wy1, wx0, wx1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[v][e] += t[e];
+      }
     }
-    reinterpret_cast<f32x4 *>(out)[idx] = acc;
+    f32x4 *dst = reinterpret_cast<f32x4 *>(out) + (idx / CG) * C4 + cg;
+#pragma unroll
+    for (int v = 0; v < PV; ++v) dst[v * CG] = acc[v];
   }
 }
 
@@ -464,7 +474,9 @@ __global__ __launch_bounds__(256) void fc_rows_kernel(const float *__restrict__ 
   // the workgroup's FC_COLS weight rows are contiguous in memory: one coalesced sweep into LDS
   for (int i = threadIdx.x; i < FC_COLS * K4; i += 256)
     reinterpret_cast<f32x4 *>(s_w)[i] = reinterpret_cast<const f32x4 *>(w + (size_t)col0 * K)[i];
-  for (int r0 = 0; r0 < rows; r0 += 64) {
+  // blockIdx.y walks the 64-row chunks (gridDim.y workgroups share them): with one row per object and hundreds of objects per
+  // call the chunks fill the chip instead of being looped over by nout / FC_COLS workgroups
+  for (int r0 = blockIdx.y * 64; r0 < rows; r0 += gridDim.y * 64) {
     const int r = r0 + lane;
     const bool live = r < rows;
     const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + (size_t)(live ? r : r0) * x_ld + g * x_gstride) + wave * kq4;
@@ -551,7 +563,7 @@ void launch_psp_pool(const float *in, int in_ld, int in_coff, float *out, int B,
   hipLaunchKernelGGL(psp_pool_kernel, dim3(50, B), dim3(512), 0, st, in, in_ld, in_coff, out, B, H, W, C);
 }
 void launch_psp_prior_sum(const float *z, float *out, int B, int H, int W, int C, hipStream_t st) {
-  hipLaunchKernelGGL(psp_prior_sum_kernel, dim3(blocks_for((long)B * H * W * (C / 4))), dim3(TPB), 0, st, z, out, B, H, W, C);
+  hipLaunchKernelGGL(psp_prior_sum_kernel, dim3(blocks_for((long)B * H * W * (C / 16))), dim3(TPB), 0, st, z, out, B, H, W, C);
 }
 void launch_up3_patches(const float *x, const int64_t *choose, float *patch, int B, int h, int wd, int N, int Npad, hipStream_t st) {
   hipLaunchKernelGGL(up3_patch_kernel, dim3(blocks_for((long)B * Npad * 9 * 16)), dim3(TPB), 0, st, x, choose, patch, B, h, wd, N, Npad);
@@ -591,8 +603,9 @@ void launch_fc_rows(const float *x, int x_ld, int x_gstride, const float *w, con
                     int nout, int groups, int relu, hipStream_t st) {
   // K % 128 == 0 and nout % FC_COLS == 0 hold for every caller (K 512 / 1024, nout 128 .. 1920)
   const size_t lds = ((size_t)FC_COLS * K + 4 * FC_COLS * 64) * sizeof(float);
-  hipLaunchKernelGGL(fc_rows_kernel, dim3(nout * groups / FC_COLS), dim3(256), lds, st, x, x_ld, x_gstride, w, bias, y, y_ld, rows, K, nout,
-                     groups, relu);
+  const int chunks = (rows + 63) / 64;
+  hipLaunchKernelGGL(fc_rows_kernel, dim3(nout * groups / FC_COLS, chunks < 8 ? chunks : 8), dim3(256), lds, st, x, x_ld, x_gstride, w, bias, y, y_ld, rows,
+                     K, nout, groups, relu);
 }
 void launch_head_final(const float *h3, const float *w_r, const float *b_r, const float *w_t, const float *b_t,
                        const float *w_c, const float *b_c, const int64_t *obj, int num_obj, float *out_r, float *out_t,
