@@ -152,14 +152,14 @@ def profile_gemm(pe, groups, steps):
 TRAFFIC_FILE = "r02_igemm_traffic.json"
 
 
-def measured_traffic(groups):
+def measured_traffic(groups, per_bucket):
     """HBM bytes per igemm launch from the committed PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE, separate passes over a
-    serial un-graphed run with --groups 1: tools/make_profiles.sh -> profiles/); None when the file is absent or the launch
-    structure differs from the profiled one."""
+    serial un-graphed run with --groups 1 --per-bucket 40: tools/make_profiles.sh -> profiles/); None when the file is absent or
+    the launch structure / batch differs from the profiled one."""
     try:
         with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
             t = json.load(f)
-        if groups != 1:
+        if groups != 1 or per_bucket != 40:
             return None
         c = t["hbm_bytes_corrected_per_dispatch"]
         return {"hbm_mb_per_launch": round(c["total"] / 1e6, 2), "read_mb": round(c["read"] / 1e6, 2), "write_mb": round(c["write"] / 1e6, 2),
@@ -600,7 +600,7 @@ def main():
             "reference_algorithm_tflops_per_gpu": round(gflop_step * args.steps / dt / 1e3, 2),
         }
         ms, fl, useful, by, n = profile_gemm(pe, groups, min(args.steps, 5))
-        traffic = measured_traffic(len(groups))
+        traffic = measured_traffic(len(groups), args.per_bucket)
         if traffic and n:
             traffic["ratio_to_algorithmic"] = round(traffic["hbm_mb_per_launch"] / (by / n / 1e6), 3)
         ach = fl / ms / 1e9 if ms > 0 else 0.0

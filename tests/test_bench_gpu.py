@@ -1,0 +1,41 @@
+"""GPU: bench.py end to end on a reduced batch -- the driver's contract for the JSON line (keys, units, the two extra objects)
+and the internal consistency of the numbers it reports."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_json_contract():
+    env = dict(os.environ, DF_BENCH_CPU_BUDGET_S="2")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--per-bucket", "4"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "poses/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value is the whole job's throughput: poses of the timed steps / their wall time
+    poses = d["config"]["objects_per_step_per_gpu"] * d["steps"]
+    assert abs(d["value"] - poses / (d["ms_per_step"] * d["steps"] / 1e3)) <= 0.01 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and 0 < r["useful_frac"] <= r["frac"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_us"] * 1e3) <= 0.02 * r["achieved"]     # GFLOP / us = PFLOP/s
+    assert r["traffic"] is None                       # the committed PMC profile is for the default batch only
+    c = d["cpu_baseline"]
+    assert c["unit"] == "poses/s" and c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["parity"]["max_add_m_vs_oracle"] < d["parity"]["tolerance_m"] == 1e-4
+    for k in ("knn", "train", "entry_point", "latency_single_object"):
+        assert k in d, k
+    assert d["entry_point"]["lost"] == 0 and d["entry_point"]["entry_point_poses_per_s"] > 0
