@@ -228,22 +228,24 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const ConvParams p) {
 
 
 // ------------------------------------------------------------------------------------------------
-// v2: the same tiling, software-pipelined so the matrix pipe never waits for the loader.
-//   * every global access is a bounds-checked buffer load (out-of-range -> 0, no branches), so the
-//     loop body is one basic block and address arithmetic, loads and LDS traffic sit between MFMAs;
-//   * 3-stage pipeline: tile kt is multiplied from LDS while tile kt+1 moves registers -> LDS and
-//     tile kt+2 is in flight from HBM/L2; one barrier per tile, placed BEFORE the last quarter of
-//     the tile's MFMAs so the next tile's first fragment reads hide under them;
-//   * epilogue through LDS: each wave transposes its accumulators so that global stores / residual
-//     loads are 16-byte vectors covering whole 128/256-byte row segments.
+// v4 -- the product kernel: the v1 tiling, with latency hidden by OCCUPANCY rather than by a software pipeline inside the wave.
+//   * every global access is a bounds-checked buffer load (out-of-range -> 0, no branches): zero padding, ragged edges
+//     and the k tail cost nothing and the loop body is one basic block;
+//   * ONE k-tile buffer in LDS (36 KB for 128x128x32) and no fragment double-buffering: <= 128 VGPRs + the accumulators,
+//     so OCC workgroups (4 / 5 / 6 for the 128x128 / 128x64 / 64x64 tile) share a CU.  Per k tile a workgroup does
+//     registers -> LDS, issues tile kt+1's loads, barrier, 2*NP MFMA groups fed by ds_read_b128, barrier; while it
+//     waits -- at a barrier, for its loads, in its prologue or its epilogue -- the other workgroups own the matrix
+//     pipes.  Measured against the 3-stage software-pipelined predecessor (2 workgroups per CU, profiles/r02_experiments):
+//     +9 % at K = 192, +5 % at K = 256, +2 % at K = 512, +1 % at K = 1024 -- the short-K launches, where prologue and
+//     epilogue are a third of a workgroup's life, gain most;
+//   * epilogue through LDS, one 32-row band at a time (the k-tile buffer is reused): global stores / residual loads are
+//     16-byte vectors covering whole 128/256-byte row segments.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT>
-__global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void igemm_f32_v4_kernel(const ConvParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
-  // BKT = k depth of one LDS tile (32 or 64): the MFMA time between two barriers is BKT/2 * TM*TN * 64 cycles,
-  // so the small 64x64 tile takes BKT = 64 to keep the barrier cost per MFMA where the 128x128 tile has it.
   constexpr int VPR = BKT / 4;                  // 16-byte vectors per tile row
   constexpr int RPP = 256 / VPR;                // tile rows staged per pass of the 256 threads
   constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;
@@ -294,20 +296,21 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
   const int in_c0 = p.in_coff;
 
   const int vec = tid % VPR, lrow = tid / VPR;
-  int a_iy0[A_ROWS], a_ix0[A_ROWS], a_off[A_ROWS];   // a_off: element offset of (b, iy0, ix0, first channel)
+  // per staged row: (iy0, ix0) of the output pixel's window origin packed as two signed 16-bit halves (H, W < 2^15 - pad:
+  // host-checked) -- the register budget of 4 workgroups per CU is exact -- and a_off, the element offset of (b, iy0, ix0, first channel)
+  int a_yx[A_ROWS], a_off[A_ROWS];
 #pragma unroll
   for (int i = 0; i < A_ROWS; ++i) {
     const int m = m0 + lrow + RPP * i;
     if (m < M) {
       const int ohw = p.OH * p.OW;
-      const int b = m / ohw, rem = m - b * ohw;
-      const int oy = rem / p.OW, ox = rem - oy * p.OW;
-      a_iy0[i] = oy * p.stride - p.pad;
-      a_ix0[i] = ox * p.stride - p.pad;
-      a_off[i] = ((b * p.H + a_iy0[i]) * p.W + a_ix0[i]) * p.in_ld + in_c0;
+      const int b = fdiv(m, p.ohw_magic, p.ohw_sh, ohw), rem = m - b * ohw;
+      const int oy = fdiv(rem, p.ow_magic, p.ow_sh, p.OW), ox = rem - oy * p.OW;
+      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+      a_yx[i] = (int)(((unsigned)iy0 << 16) | ((unsigned)ix0 & 0xffffu));
+      a_off[i] = ((b * p.H + iy0) * p.W + ix0) * p.in_ld + in_c0;
     } else {
-      a_iy0[i] = -(1 << 28);
-      a_ix0[i] = 0;
+      a_yx[i] = (int)0x80000000u;      // iy0 = -32768: never inside the image
       a_off[i] = 0;
     }
   }
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
     const int doff = (dy * p.W + dx) * p.in_ld + c;
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
-      const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+      const int iy = (a_yx[i] >> 16) + dy, ix = (int)(short)a_yx[i] + dx;
       // bitwise (not short-circuit) so no control flow is generated: the loop body stays one basic block
       const int ok = kok & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W);
       unsigned off = ok ? (unsigned)(a_off[i] + doff) * 4u : 0xffffffffu;
@@ -355,8 +358,8 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
       rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0);
     }
   };
-  auto write_lds = [&](int buf) {
-    float *sA = smem + buf * TILE, *sB = sA + BM * LDK;
+  auto write_lds = [&]() {
+    float *sA = smem, *sB = sA + BM * LDK;
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) *reinterpret_cast<u32x4 *>(sA + (lrow + RPP * i) * LDK + vec * 4) = ra[i];
 #pragma unroll
@@ -367,9 +370,9 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
   const int fa = (wm * WM + li) * LDK + lh * 4;                  // this lane's A-fragment base (floats)
   const int fb = BM * LDK + (wn * WN + li) * LDK + lh * 4;
   // fragments of two 8-wide k groups: [half][tile]
-  f32x4 a0[2][TM], b0[2][TN], a1[2][TM], b1[2][TN];
-  auto read_frags = [&](int buf, int gpair, f32x4 (&a)[2][TM], f32x4 (&b)[2][TN]) {
-    const float *base = smem + buf * TILE;
+  f32x4 a0[2][TM], b0[2][TN];
+  auto read_frags = [&](int gpair, f32x4 (&a)[2][TM], f32x4 (&b)[2][TN]) {
+    const float *base = smem;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -396,65 +399,28 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
   };
 
-  // prologue: tile 0 -> LDS, tile 1 -> registers
   DF_TRACE(0);
   issue_loads(0);
-  write_lds(0);
-  issue_loads(1);
-  __syncthreads();
-  read_frags(0, 0, a0, b0);
   DF_TRACE(1);
   for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    // pair pp multiplies out of register set pp&1 while pair pp+1 is read into the other set
+    write_lds();                         // tile kt: registers -> LDS (waits for its loads)
+    issue_loads(kt + 1);                 // tile kt+1 flies while tile kt multiplies (zeros past the end)
+    __syncthreads();
 #pragma unroll
-    for (int pp = 0; pp < NP - 1; ++pp) {
-      if (pp & 1) read_frags(buf, pp + 1, a0, b0); else read_frags(buf, pp + 1, a1, b1);
-      if (pp == NP / 2 - 1) {
-        // register -> LDS hand-over of tile kt+1 and the issue of tile kt+2 sit mid-tile: the loads then have
-        // about a full tile of MFMA time to land before their ds_write
-        __builtin_amdgcn_sched_barrier(0);
-        write_lds(buf ^ 1);             // tile kt+1 (zeros past the end): registers -> the idle buffer
-        issue_loads(kt + 2);            // tile kt+2 starts its trip; consumed one full tile later
-      }
-      if (pp & 1) { mfma_group(a1[0], b1[0]); mfma_group(a1[1], b1[1]); }
-      else { mfma_group(a0[0], b0[0]); mfma_group(a0[1], b0[1]); }
-      if (pp == NP / 2 - 1) {
-        // Spread the loader's address arithmetic, the ds_writes and the buffer loads evenly over the MFMAs of
-        // this pair: an f32 MFMA keeps the matrix pipe busy for 64 cycles, during which the same wave can issue
-        // ~10 other instructions for free -- but a run of 40 of them between two MFMAs leaves the pipe idle.
-#pragma unroll
-        for (int q = 0; q < 8 * TM * TN; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, TM * TN == 4 ? 3 : (TM * TN == 2 ? 5 : 8), 0);     // VALU
-          __builtin_amdgcn_sched_group_barrier(0x004, TM * TN == 4 ? 1 : (TM * TN == 2 ? 2 : 3), 0);     // SALU
-          __builtin_amdgcn_sched_group_barrier(0x090, TM * TN == 4 ? 1 : 2, 0);                          // DS | VMEM
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+    for (int pp = 0; pp < NP; ++pp) {
+      read_frags(pp, a0, b0);
+      mfma_group(a0[0], b0[0]);
+      mfma_group(a0[1], b0[1]);
     }
-    __syncthreads();                    // everyone has read tile kt out of `buf`; tile kt+1 is complete in buf^1
-    read_frags(buf ^ 1, 0, a0, b0);     // lands while the last pair of tile kt multiplies
-    __builtin_amdgcn_sched_barrier(0);  // hipcc would otherwise hoist these MFMAs above the barrier
-    mfma_group(a1[0], b1[0]);
-    mfma_group(a1[1], b1[1]);
+    __syncthreads();                     // every wave has read tile kt before tile kt+1 overwrites it
   }
-  __syncthreads();                    // the speculative fragment reads above are done before smem is reused
   DF_TRACE(2);
 
-  // ---- epilogue: accumulators -> LDS (per-wave region) -> 16-byte row segments ----
+  // ---- epilogue: accumulators -> LDS (per-wave region) -> 16-byte row segments, one 32-row band of the wave tile at a time (the
+  // single 36 KB buffer holds 4 waves x 32 rows x (WN + 4) floats)
   constexpr int EP_LD = WN + 4;
-  float *ep = smem + wave * (WM * EP_LD);
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) ep[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * EP_LD + j * 32 + li] = acc[i][j][e];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
+  static_assert(4 * 32 * EP_LD <= TILE, "epilogue staging must fit the k-tile buffer");
+  float *ep = smem + wave * (32 * EP_LD);
   const float slope = (p.act == ACT_PRELU) ? p.prelu[0] : 0.f;
   const int grp = (p.rows_per_group > 0) ? m0 / p.rows_per_group : 0;
   const float *bias = p.bias ? p.bias + z * p.z_bias + (p.bias_group_ld > 0 ? (size_t)grp * p.bias_group_ld : 0) : nullptr;
@@ -467,48 +433,55 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
   if (bias && nok) bv = *reinterpret_cast<const f32x4 *>(bias + n);
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   const int valid_rows = p.rows_per_group > 0 ? p.rows_valid - (m0 - grp * p.rows_per_group) : (1 << 30);
-  // the residual rows are requested half a wave tile at a time (two trips to memory instead of one per group of rows)
-  constexpr int NPS = WM / ERPP, HPS = NPS / 2;
+  constexpr int BPS = 32 / ERPP;         // passes per 32-row band
 #pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-  f32x4 rres[HPS];
-  if (p.res) {
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int q = 0; q < HPS; ++q) {
-      const int m = m0 + wm * WM + (hh * HPS + q) * ERPP + r0;
-      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-      if (nok && m < M) rv = *reinterpret_cast<const f32x4 *>(p.res + (size_t)m * p.res_ld + p.res_coff + n);
-      rres[q] = rv;
-    }
-  }
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-  for (int q = 0; q < HPS; ++q) {
-    const int ps = hh * HPS + q;
-    const int row = ps * ERPP + r0;
-    const int m = m0 + wm * WM + row;
-    const bool ok = nok && m < M;
-    f32x4 v = *reinterpret_cast<const f32x4 *>(ep + row * EP_LD + c4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += bv[e];
+      for (int e = 0; e < 16; ++e) ep[((e & 3) + 8 * (e >> 2) + 4 * lh) * EP_LD + j * 32 + li] = acc[i][j][e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x4 rres[BPS];
     if (p.res) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += rres[q][e];
+      for (int q = 0; q < BPS; ++q) {
+        const int m = m0 + wm * WM + i * 32 + q * ERPP + r0;
+        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+        if (nok && m < M) rv = *reinterpret_cast<const f32x4 *>(p.res + (size_t)m * p.res_ld + p.res_coff + n);
+        rres[q] = rv;
+      }
     }
-    if (p.act == ACT_RELU) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-    } else if (p.act == ACT_PRELU) {
+    for (int q = 0; q < BPS; ++q) {
+      const int row = i * 32 + q * ERPP + r0;
+      const int m = m0 + wm * WM + row;
+      const bool ok = nok && m < M;
+      f32x4 v = *reinterpret_cast<const f32x4 *>(ep + (q * ERPP + r0) * EP_LD + c4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+      for (int e = 0; e < 4; ++e) v[e] += bv[e];
+      if (p.res) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += rres[q][e];
+      }
+      if (p.act == ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      } else if (p.act == ACT_PRELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+      }
+      if (ok && p.out) *reinterpret_cast<f32x4 *>(p.out + (size_t)m * p.out_ld + out_coff + n) = v;
+      if (p.colsum) {
+        const bool real = ok && wm * WM + row < valid_rows;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[e] += real ? v[e] : 0.f;
+      }
     }
-    if (ok && p.out) *reinterpret_cast<f32x4 *>(p.out + (size_t)m * p.out_ld + out_coff + n) = v;
-    if (p.colsum) {
-      // rows of this tile that count: a tile never straddles groups, so (m % rows_per_group) = (m0 % rows_per_group) + local row
-      const bool real = ok && wm * WM + row < valid_rows;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) csum[e] += real ? v[e] : 0.f;
-    }
-  }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                 // the band is read out before the next one lands in the same rows
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   if (p.colsum) {
     // lanes with equal (lane % LPR) hold different rows of the same 4 columns: fold them (fixed order)
@@ -794,28 +767,43 @@ __global__ __launch_bounds__(256) void bias_reduce_kernel(const float *__restric
 
 struct TileCfg { int bm, bn, wmv; };     // workgroup tile and waves along M
 
+// Launches the product kernel (v4) takes; the rest -- input dilation (the data gradient of a strided convolution), operands of
+// 4 GB or more per z slice (a buffer descriptor's reach), channel offsets / strides that are not multiples of 4 -- go to v1.
+bool takes_v4(const ConvParams &p) {
+  static const bool force_v1 = getenv("DF_IGEMM_V1") != nullptr;   // dev switch: A/B against the un-pipelined kernel; read once
+  const size_t in_bytes = (size_t)p.B * p.H * p.W * p.in_ld * sizeof(float);      // per z slice
+  const size_t w_bytes = (size_t)p.Cout * p.KH * p.KW * p.Cin * sizeof(float);
+  return !force_v1 && p.up == 1 && p.H + p.pad < 32768 && p.W + p.pad < 32768 && in_bytes < (1ull << 32) && w_bytes < (1ull << 32) && p.Cout % 4 == 0 && p.out_ld % 4 == 0 &&
+         p.out_coff % 4 == 0 && p.z_out_coff % 4 == 0 && (!p.res || (p.res_ld % 4 == 0 && p.res_coff % 4 == 0)) &&
+         (!p.bias || (p.bias_group_ld % 4 == 0 && p.z_bias % 4 == 0));
+}
+
 TileCfg pick_cfg(const ConvParams &p) {
   const long M = (long)p.B * p.OH * p.OW;
-  // (Row-grouped launches -- fused mean / per-object bias -- need BM | rows_per_group; both tiles divide the
+  // (Row-grouped launches -- fused mean / per-object bias -- need BM | rows_per_group; every tile divides the
   // 128-padded groups the engine uses.)  Pick the tile that minimises  ceil(tiles / 256 CUs) * tile_area / efficiency : the chip
   // finishes when its most loaded CU does, so a 128x128 grid of e.g. 800 tiles (4 rounds for 3.1 rounds
-  // of work) loses to the same problem cut into 3200 64x64 tiles (13 rounds for 12.5).
+  // of work) loses to the same problem cut into 3200 64x64 tiles (13 rounds for 12.5), and Cout = 576 (4.5 column
+  // tiles of 128) is cut into 9 columns of 128x64 tiles.
   // The fused column sum adds rows in per-wave groups: keep that grouping independent of the batch size (so
   // a batched call stays bit-identical to solo calls) by always using the 128x128 tile for it.
   if (p.colsum || !p.out) return {128, 128, 2};     // (!p.out: the same launch while its partial buffer is being sized)
+  const bool v4 = takes_v4(p);                      // v1 has the two square tiles only
+  static const char *const tile_env = getenv("DF_IGEMM_TILE");      // dev switch for A/B runs; read once
+  if (tile_env) {
+    if (tile_env[0] == 'a') return {128, 128, 2};
+    if (tile_env[0] == 'b' && v4) return {128, 64, 2};
+    if (tile_env[0] == 'c' || tile_env[0] == 'b') return {64, 64, 2};
+  }
   auto cost = [&](int bm, int bn, double eff) {
     const long tiles = ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * p.zcount;
     const long rounds = (tiles + 255) / 256;
     return (double)rounds * bm * bn / eff;
   };
-  static const char *const tile_env = getenv("DF_IGEMM_TILE");      // dev switch for A/B runs; read once
-  if (tile_env) {
-    if (tile_env[0] == 'a') return {128, 128, 2};
-    if (tile_env[0] == 'c') return {64, 64, 2};
-  }
-  // (a 128x64 tile was measured too: never better than 64x64, up to 1.8x worse on small grids)
-  const double c128 = cost(128, 128, 1.0), c64 = cost(64, 64, 0.96);
-  if (p.Cout >= 128 && c128 <= c64) return {128, 128, 2};
+  // efficiencies from the per-shape table of a bench step run with each tile forced (tools/dev/gemm_list.sh)
+  const double ca = p.Cout >= 128 ? cost(128, 128, 1.0) : 1e300, cb = v4 ? cost(128, 64, 0.99) : 1e300, cc = cost(64, 64, 0.96);
+  if (ca <= cb && ca <= cc) return {128, 128, 2};
+  if (cb <= cc) return {128, 64, 2};
   return {64, 64, 2};
 }
 
@@ -849,7 +837,9 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
   if (M * (long)p.out_ld >= (1L << 40) || (long)p.B * p.H * p.W >= (1L << 31))
     return set_error(DF_ERR_ARG, "conv: tensor too large for 32-bit pixel indexing");
   const TileCfg c = pick_cfg(p);
-  ConvParams pl = p;       // launch copy: + the column-tile group width
+  ConvParams pl = p;       // launch copy: + the column-tile group width and the division magics
+  make_fdiv((long)p.OH * p.OW, pl.ohw_magic, pl.ohw_sh);
+  make_fdiv(p.OW, pl.ow_magic, pl.ow_sh);
   {
     const size_t slice = (size_t)c.bn * p.KH * p.KW * p.Cin * sizeof(float);       // weights of one column tile
     const long tn = (p.Cout + c.bn - 1) / c.bn;
@@ -860,9 +850,8 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
     return set_error(DF_ERR_ARG, "conv: rows_per_group must be a multiple of %d", c.bm);
   const long tiles = ((M + c.bm - 1) / c.bm) * ((p.Cout + c.bn - 1) / c.bn);
   dim3 grid((unsigned)tiles, 1, p.zcount);
-  const size_t lds = (size_t)2 * (c.bm + c.bn) * LDK * sizeof(float);
-  // 72 KiB of dynamic LDS for the 128x128 tiles: above the 64 KiB default cap.  The attribute is per device (a process may
-  // drive several): set once for every device a launch is seen on.
+  // v1's 128x128 tile double-buffers 72 KiB of dynamic LDS: above the 64 KiB default cap.  The attribute is per device (a process
+  // may drive several): set once for every device a launch is seen on.  (v4's single k-tile buffer is 36 KiB at most.)
   {
     static bool attr_done[64] = {};
     int dev = 0;
@@ -870,26 +859,22 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
     if (dev >= 0 && dev < 64 && !attr_done[dev]) {
       hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_f32_kernel<128, 128, 2, 2>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * LDK * (int)sizeof(float));
-      hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_f32_v2_kernel<128, 128, 2, 2, 32>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 36 * (int)sizeof(float));
       attr_done[dev] = true;
     }
   }
-  static const bool force_v1 = getenv("DF_IGEMM_V1") != nullptr;   // dev switch: A/B against the un-pipelined kernel; read once
-  const size_t in_bytes = (size_t)p.B * p.H * p.W * p.in_ld * sizeof(float);      // per z slice
-  const size_t w_bytes = (size_t)p.Cout * p.KH * p.KW * p.Cin * sizeof(float);
-  const bool v2 = !force_v1 && p.up == 1 && in_bytes < (1ull << 32) && w_bytes < (1ull << 32) && p.Cout % 4 == 0 && p.out_ld % 4 == 0 &&
-                  p.out_coff % 4 == 0 && p.z_out_coff % 4 == 0 && (!p.res || (p.res_ld % 4 == 0 && p.res_coff % 4 == 0)) &&
-                  (!p.bias || (p.bias_group_ld % 4 == 0 && p.z_bias % 4 == 0));
-  if (v2) {
+  constexpr size_t ROW = 36 * sizeof(float);      // one padded k-tile row (BKT = 32)
+  if (takes_v4(p)) {
+    // workgroups per CU: 4 / 5 / 6 (the register budget amdgpu_waves_per_eu leaves each: 128 / 102 / 85 VGPRs + AGPRs)
     if (c.bm == 128 && c.bn == 128)
-      hipLaunchKernelGGL((igemm_f32_v2_kernel<128, 128, 2, 2, 32>), grid, dim3(256), (size_t)2 * 256 * 36 * sizeof(float), st, pl);
+      hipLaunchKernelGGL((igemm_f32_v4_kernel<128, 128, 2, 2, 32, 4>), grid, dim3(256), 256 * ROW, st, pl);
+    else if (c.bm == 128)
+      hipLaunchKernelGGL((igemm_f32_v4_kernel<128, 64, 2, 2, 32, 5>), grid, dim3(256), 192 * ROW, st, pl);
     else      // (a BK = 64 form of the small tile was measured: 0.85-1.0x, dropped)
-      hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2, 32>), grid, dim3(256), (size_t)2 * 128 * 36 * sizeof(float), st, pl);
-  } else if (c.bm == 128 && c.bn == 128) {
-    hipLaunchKernelGGL((igemm_f32_kernel<128, 128, 2, 2>), grid, dim3(256), lds, st, p);
+      hipLaunchKernelGGL((igemm_f32_v4_kernel<64, 64, 2, 2, 32, 6>), grid, dim3(256), 128 * ROW, st, pl);
+  } else if (c.bm == 128) {
+    hipLaunchKernelGGL((igemm_f32_kernel<128, 128, 2, 2>), grid, dim3(256), (size_t)2 * 256 * LDK * sizeof(float), st, p);
   } else {
-    hipLaunchKernelGGL((igemm_f32_kernel<64, 64, 2, 2>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((igemm_f32_kernel<64, 64, 2, 2>), grid, dim3(256), (size_t)2 * 128 * LDK * sizeof(float), st, p);
   }
   return check_launch("igemm");
 }
