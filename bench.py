@@ -604,7 +604,7 @@ def main():
         if traffic and n:
             traffic["ratio_to_algorithmic"] = round(traffic["hbm_mb_per_launch"] / (by / n / 1e6), 3)
         ach = fl / ms / 1e9 if ms > 0 else 0.0
-        out["roofline"] = {"kernel": "igemm_f32_v2_kernel (implicit-GEMM conv / per-point / Winograd-domain GEMM, v_mfma_f32_32x32x2_f32; all launches of a step)",
+        out["roofline"] = {"kernel": "igemm_f32_v4_kernel (implicit-GEMM conv / per-point / Winograd-domain GEMM, v_mfma_f32_32x32x2_f32; all launches of a step)",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / FP32_PEAK_TFLOPS, 4),
                            "useful_frac": round(useful / ms / 1e9 / FP32_PEAK_TFLOPS, 4) if ms > 0 else 0.0,

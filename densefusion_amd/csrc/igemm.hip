@@ -228,14 +228,314 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const ConvParams p) {
 
 
 // ------------------------------------------------------------------------------------------------
-// v4 -- the product kernel: the v1 tiling, with latency hidden by OCCUPANCY rather than by a software pipeline inside the wave.
+// v2 -- the latency kernel, for grids that cannot fill the chip (under two workgroups per CU: single-frame training passes,
+// the per-object head GEMMs of a small batch).  The v1 tiling, software-pipelined inside the wave so that a workgroup ALONE on
+// its CU keeps the matrix pipe fed (81 % MFMA busy solo, tools/dev/igemm_trace.hip); 72 KB of LDS and ~200 registers, so
+// at most two workgroups per CU -- on full grids v4 below (4-6 per CU) is 1-9 % faster and takes over.
+//   * every global access is a bounds-checked buffer load (out-of-range -> 0, no branches), so the
+//     loop body is one basic block and address arithmetic, loads and LDS traffic sit between MFMAs;
+//   * 3-stage pipeline: tile kt is multiplied from LDS while tile kt+1 moves registers -> LDS and
+//     tile kt+2 is in flight from HBM/L2; one barrier per tile, placed BEFORE the last quarter of
+//     the tile's MFMAs so the next tile's first fragment reads hide under them;
+//   * epilogue through LDS: each wave transposes its accumulators so that global stores / residual
+//     loads are 16-byte vectors covering whole 128/256-byte row segments.
+// Same k order and MFMA sequence per output element as v4: which of the two a launch takes never changes a bit of its result.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT>
+__global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  // BKT = k depth of one LDS tile (32 or 64): the MFMA time between two barriers is BKT/2 * TM*TN * 64 cycles,
+  // so the small 64x64 tile takes BKT = 64 to keep the barrier cost per MFMA where the 128x128 tile has it.
+  constexpr int VPR = BKT / 4;                  // 16-byte vectors per tile row
+  constexpr int RPP = 256 / VPR;                // tile rows staged per pass of the 256 threads
+  constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;
+  constexpr int LDK = BKT + 4;                  // padded row: ds_read_b128 of 16 rows hits 64 distinct banks
+  constexpr int BK = BKT;
+  constexpr int NP = BKT / 16;                  // pairs of 8-wide k groups per tile
+  constexpr int TILE = (BM + BN) * LDK;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int M = p.B * p.OH * p.OW;
+  const int K = p.KH * p.KW * p.Cin;
+  const int tiles_n = (p.Cout + BN - 1) / BN;
+  int wgid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  // column-tile groups: when the weight operand is too big for an XCD's L2 (4 MB), the tiles are walked group by group
+  // (p.ngroup column tiles, all row blocks, next group ...) so that the group's weight slice stays L2-resident while the
+  // activation rows stream through once per group instead of every column tile missing on both operands
+  int n_tile, m_tile;
+  {
+    const int GN = p.ngroup > 0 && p.ngroup < tiles_n ? p.ngroup : tiles_n;
+    const int tiles_m = (int)(gridDim.x / tiles_n);
+    const int full = tiles_m * GN;
+    const int g = wgid / full, rem = wgid - g * full;
+    const int gw = min(GN, tiles_n - g * GN);
+    m_tile = rem / gw;
+    n_tile = g * GN + (rem - m_tile * gw);
+  }
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+  const int z = blockIdx.z;
+  const int out_coff = p.out_coff + (int)(z * p.z_out_coff);
+
+  // buffer descriptors (wave-uniform): reads past num_records return 0
+  // (one descriptor per z slice: a z-batched launch may span more than the 4 GB a descriptor can address)
+  const unsigned in_bytes = (unsigned)((size_t)p.B * p.H * p.W * p.in_ld * sizeof(float));
+  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in + (size_t)z * p.z_in_coff), 0, in_bytes, 0x00020000);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wgt + (size_t)z * p.z_wgt), 0,
+                                                      (unsigned)((size_t)p.Cout * K * sizeof(float)), 0x00020000);
+  const int in_c0 = p.in_coff;
+
+  const int vec = tid % VPR, lrow = tid / VPR;
+  int a_iy0[A_ROWS], a_ix0[A_ROWS], a_off[A_ROWS];   // a_off: element offset of (b, iy0, ix0, first channel)
+#pragma unroll
+  for (int i = 0; i < A_ROWS; ++i) {
+    const int m = m0 + lrow + RPP * i;
+    if (m < M) {
+      const int ohw = p.OH * p.OW;
+      const int b = m / ohw, rem = m - b * ohw;
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      a_iy0[i] = oy * p.stride - p.pad;
+      a_ix0[i] = ox * p.stride - p.pad;
+      a_off[i] = ((b * p.H + a_iy0[i]) * p.W + a_ix0[i]) * p.in_ld + in_c0;
+    } else {
+      a_iy0[i] = -(1 << 28);
+      a_ix0[i] = 0;
+      a_off[i] = 0;
+    }
+  }
+  int b_off[B_ROWS];
+#pragma unroll
+  for (int i = 0; i < B_ROWS; ++i) {
+    const int n = n0 + lrow + RPP * i;
+    b_off[i] = n < p.Cout ? n * K : -1;
+  }
+  const bool one_tap = (p.KH * p.KW == 1);
+  const int cin_shift = 31 - __builtin_clz(p.Cin);
+  const int nkt = (K + BK - 1) / BK;
+
+  // branch-free k -> (tap, channel) decode: single-tap layers use shift 31 / mask ~0 (tap = 0, c = k)
+  const int k_shift = one_tap ? 31 : cin_shift;
+  const int c_mask = one_tap ? 0x7fffffff : p.Cin - 1;
+  const int kw_magic = (65536 + p.KW - 1) / p.KW;     // tap / KW == (tap * kw_magic) >> 16 for tap < 64
+
+  u32x4 ra[A_ROWS], rb[B_ROWS];
+  auto issue_loads = [&](int kt) {
+    // the tile index goes through an opaque asm so that the address arithmetic below cannot be strength-reduced
+    // into loop-header induction updates: it has to stay here, between the MFMAs, where its issue slots are free
+    asm volatile("" : "+s"(kt));
+    const int k = kt * BK + vec * 4;
+    const int kok = k < K;
+    const int tap = k >> k_shift;
+    const int c = k & c_mask;
+    const int ky = (tap * kw_magic) >> 16, kx = tap - ky * p.KW;
+    const int dy = ky * p.dil, dx = kx * p.dil;
+    const int doff = (dy * p.W + dx) * p.in_ld + c;
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+      const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+      // bitwise (not short-circuit) so no control flow is generated: the loop body stays one basic block
+      const int ok = kok & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W);
+      unsigned off = ok ? (unsigned)(a_off[i] + doff) * 4u : 0xffffffffu;
+      asm("" : "+v"(off));      // opaque: keeps hipcc from turning the select into two branchy loads
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) {
+      const int ok = kok & (int)(b_off[i] >= 0);
+      unsigned off = ok ? (unsigned)(b_off[i] + k) * 4u : 0xffffffffu;
+      asm("" : "+v"(off));
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0);
+    }
+  };
+  auto write_lds = [&](int buf) {
+    float *sA = smem + buf * TILE, *sB = sA + BM * LDK;
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) *reinterpret_cast<u32x4 *>(sA + (lrow + RPP * i) * LDK + vec * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<u32x4 *>(sB + (lrow + RPP * i) * LDK + vec * 4) = rb[i];
+  };
+
+  const int li = lane & 31, lh = lane >> 5;
+  const int fa = (wm * WM + li) * LDK + lh * 4;                  // this lane's A-fragment base (floats)
+  const int fb = BM * LDK + (wn * WN + li) * LDK + lh * 4;
+  // fragments of two 8-wide k groups: [half][tile]
+  f32x4 a0[2][TM], b0[2][TN], a1[2][TM], b1[2][TN];
+  auto read_frags = [&](int buf, int gpair, f32x4 (&a)[2][TM], f32x4 (&b)[2][TN]) {
+    const float *base = smem + buf * TILE;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[h][i] = *reinterpret_cast<const f32x4 *>(base + fa + i * 32 * LDK + (gpair * 2 + h) * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[h][j] = *reinterpret_cast<const f32x4 *>(base + fb + j * 32 * LDK + (gpair * 2 + h) * 8);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  auto mfma_group = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+  };
+
+  // prologue: tile 0 -> LDS, tile 1 -> registers
+  DF_TRACE(0);
+  issue_loads(0);
+  write_lds(0);
+  issue_loads(1);
+  __syncthreads();
+  read_frags(0, 0, a0, b0);
+  DF_TRACE(1);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    // pair pp multiplies out of register set pp&1 while pair pp+1 is read into the other set
+#pragma unroll
+    for (int pp = 0; pp < NP - 1; ++pp) {
+      if (pp & 1) read_frags(buf, pp + 1, a0, b0); else read_frags(buf, pp + 1, a1, b1);
+      if (pp == NP / 2 - 1) {
+        // register -> LDS hand-over of tile kt+1 and the issue of tile kt+2 sit mid-tile: the loads then have
+        // about a full tile of MFMA time to land before their ds_write
+        __builtin_amdgcn_sched_barrier(0);
+        write_lds(buf ^ 1);             // tile kt+1 (zeros past the end): registers -> the idle buffer
+        issue_loads(kt + 2);            // tile kt+2 starts its trip; consumed one full tile later
+      }
+      if (pp & 1) { mfma_group(a1[0], b1[0]); mfma_group(a1[1], b1[1]); }
+      else { mfma_group(a0[0], b0[0]); mfma_group(a0[1], b0[1]); }
+      if (pp == NP / 2 - 1) {
+        // Spread the loader's address arithmetic, the ds_writes and the buffer loads evenly over the MFMAs of
+        // this pair: an f32 MFMA keeps the matrix pipe busy for 64 cycles, during which the same wave can issue
+        // ~10 other instructions for free -- but a run of 40 of them between two MFMAs leaves the pipe idle.
+#pragma unroll
+        for (int q = 0; q < 8 * TM * TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, TM * TN == 4 ? 3 : (TM * TN == 2 ? 5 : 8), 0);     // VALU
+          __builtin_amdgcn_sched_group_barrier(0x004, TM * TN == 4 ? 1 : (TM * TN == 2 ? 2 : 3), 0);     // SALU
+          __builtin_amdgcn_sched_group_barrier(0x090, TM * TN == 4 ? 1 : 2, 0);                          // DS | VMEM
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();                    // everyone has read tile kt out of `buf`; tile kt+1 is complete in buf^1
+    read_frags(buf ^ 1, 0, a0, b0);     // lands while the last pair of tile kt multiplies
+    __builtin_amdgcn_sched_barrier(0);  // hipcc would otherwise hoist these MFMAs above the barrier
+    mfma_group(a1[0], b1[0]);
+    mfma_group(a1[1], b1[1]);
+  }
+  __syncthreads();                    // the speculative fragment reads above are done before smem is reused
+  DF_TRACE(2);
+
+  // ---- epilogue: accumulators -> LDS (per-wave region) -> 16-byte row segments ----
+  constexpr int EP_LD = WN + 4;
+  float *ep = smem + wave * (WM * EP_LD);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ep[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * EP_LD + j * 32 + li] = acc[i][j][e];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  const float slope = (p.act == ACT_PRELU) ? p.prelu[0] : 0.f;
+  const int grp = (p.rows_per_group > 0) ? m0 / p.rows_per_group : 0;
+  const float *bias = p.bias ? p.bias + z * p.z_bias + (p.bias_group_ld > 0 ? (size_t)grp * p.bias_group_ld : 0) : nullptr;
+  constexpr int LPR = WN / 4;            // lanes per row
+  constexpr int ERPP = 64 / LPR;         // rows per pass
+  const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+  const int n = n0 + wn * WN + c4;
+  const bool nok = n < p.Cout;           // Cout % 4 == 0 (host-checked): a vector is all-in or all-out
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias && nok) bv = *reinterpret_cast<const f32x4 *>(bias + n);
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  const int valid_rows = p.rows_per_group > 0 ? p.rows_valid - (m0 - grp * p.rows_per_group) : (1 << 30);
+  // the residual rows are requested half a wave tile at a time (two trips to memory instead of one per group of rows)
+  constexpr int NPS = WM / ERPP, HPS = NPS / 2;
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+  f32x4 rres[HPS];
+  if (p.res) {
+#pragma unroll
+    for (int q = 0; q < HPS; ++q) {
+      const int m = m0 + wm * WM + (hh * HPS + q) * ERPP + r0;
+      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+      if (nok && m < M) rv = *reinterpret_cast<const f32x4 *>(p.res + (size_t)m * p.res_ld + p.res_coff + n);
+      rres[q] = rv;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < HPS; ++q) {
+    const int ps = hh * HPS + q;
+    const int row = ps * ERPP + r0;
+    const int m = m0 + wm * WM + row;
+    const bool ok = nok && m < M;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(ep + row * EP_LD + c4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += bv[e];
+    if (p.res) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += rres[q][e];
+    }
+    if (p.act == ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    } else if (p.act == ACT_PRELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+    }
+    if (ok && p.out) *reinterpret_cast<f32x4 *>(p.out + (size_t)m * p.out_ld + out_coff + n) = v;
+    if (p.colsum) {
+      // rows of this tile that count: a tile never straddles groups, so (m % rows_per_group) = (m0 % rows_per_group) + local row
+      const bool real = ok && wm * WM + row < valid_rows;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) csum[e] += real ? v[e] : 0.f;
+    }
+  }
+  }
+  if (p.colsum) {
+    // lanes with equal (lane % LPR) hold different rows of the same 4 columns: fold them (fixed order)
+#pragma unroll
+    for (int d = 32; d >= LPR; d >>= 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) csum[e] += __shfl_xor(csum[e], d);
+    if (lane < LPR && nok)
+      *reinterpret_cast<f32x4 *>(p.colsum + ((size_t)z * (gridDim.x / tiles_n) * WAVES_M + (size_t)m_tile * WAVES_M + wm) * p.Cout + n) = csum;
+  }
+  DF_TRACE(3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// v4 -- the throughput kernel (every grid of two or more workgroups per CU: > 99 % of the inference step's GEMM time): the v1
+// tiling, with latency hidden by OCCUPANCY rather than by a software pipeline inside the wave.
 //   * every global access is a bounds-checked buffer load (out-of-range -> 0, no branches): zero padding, ragged edges
 //     and the k tail cost nothing and the loop body is one basic block;
 //   * ONE k-tile buffer in LDS (36 KB for 128x128x32) and no fragment double-buffering: <= 128 VGPRs + the accumulators,
 //     so OCC workgroups (4 / 5 / 6 for the 128x128 / 128x64 / 64x64 tile) share a CU.  Per k tile a workgroup does
 //     registers -> LDS, issues tile kt+1's loads, barrier, 2*NP MFMA groups fed by ds_read_b128, barrier; while it
 //     waits -- at a barrier, for its loads, in its prologue or its epilogue -- the other workgroups own the matrix
-//     pipes.  Measured against the 3-stage software-pipelined predecessor (2 workgroups per CU, profiles/r02_experiments):
+//     pipes.  Measured against v2 on the full grids of the inference step (2 workgroups per CU; tools/dev/gemm_list.sh):
 //     +9 % at K = 192, +5 % at K = 256, +2 % at K = 512, +1 % at K = 1024 -- the short-K launches, where prologue and
 //     epilogue are a third of a workgroup's life, gain most;
 //   * epilogue through LDS, one 32-row band at a time (the k-tile buffer is reused): global stores / residual loads are
@@ -859,11 +1159,20 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
     if (dev >= 0 && dev < 64 && !attr_done[dev]) {
       hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_f32_kernel<128, 128, 2, 2>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * LDK * (int)sizeof(float));
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_f32_v2_kernel<128, 128, 2, 2, 32>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 36 * (int)sizeof(float));
       attr_done[dev] = true;
     }
   }
   constexpr size_t ROW = 36 * sizeof(float);      // one padded k-tile row (BKT = 32)
-  if (takes_v4(p)) {
+  // grids under two workgroups per CU: the software-pipelined kernel (training, 1 / 8 frames per pass: 142 -> 154 / 670 -> 696 frames/s)
+  static const long lowocc = getenv("DF_IGEMM_LOWOCC") ? atol(getenv("DF_IGEMM_LOWOCC")) : 512;    // dev switch; read once
+  if (takes_v4(p) && tiles * p.zcount < lowocc && c.bn == c.bm) {
+    if (c.bm == 128)
+      hipLaunchKernelGGL((igemm_f32_v2_kernel<128, 128, 2, 2, 32>), grid, dim3(256), (size_t)2 * 256 * 36 * sizeof(float), st, pl);
+    else
+      hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2, 32>), grid, dim3(256), (size_t)2 * 128 * 36 * sizeof(float), st, pl);
+  } else if (takes_v4(p)) {
     // workgroups per CU: 4 / 5 / 6 (the register budget amdgpu_waves_per_eu leaves each: 128 / 102 / 85 VGPRs + AGPRs)
     if (c.bm == 128 && c.bn == 128)
       hipLaunchKernelGGL((igemm_f32_v4_kernel<128, 128, 2, 2, 32, 4>), grid, dim3(256), 256 * ROW, st, pl);

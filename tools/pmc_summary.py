@@ -16,6 +16,7 @@ def main():
     out, needle, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
     csv.field_size_limit(1 << 30)
     sums, disp, dur = {}, {}, []
+    by_grid = {}           # (grid size, kernel template arguments) -> counter -> [sum, dispatches]
     for d in dirs:
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             seen = set()
@@ -25,6 +26,10 @@ def main():
                         continue
                     c = row["Counter_Name"]
                     sums[c] = sums.get(c, 0.0) + float(row["Counter_Value"])
+                    name = row["Kernel_Name"]
+                    gkey = f'{row.get("Grid_Size", "?")} {name[name.find("<"):name.find(">") + 1]}'
+                    e = by_grid.setdefault(gkey, {}).setdefault(c, [0.0, 0])
+                    e[0] += float(row["Counter_Value"]); e[1] += 1
                     disp.setdefault(c, set()).add((path, row["Dispatch_Id"]))
                     if (path, row["Dispatch_Id"]) not in seen:
                         seen.add((path, row["Dispatch_Id"]))
@@ -39,6 +44,9 @@ def main():
         rd = pd.get("FETCH_SIZE", 0.0) * 1024 * 2          # KB -> B, gfx950 half-count correction
         wr = pd.get("WRITE_SIZE", 0.0) * 1024
         res["hbm_bytes_corrected_per_dispatch"] = {"read": rd, "write": wr, "total": rd + wr}
+    # per launch shape (grid size = tiles * 256 threads [* z]): where the traffic above the algorithmic bytes comes from
+    res["per_grid_kb"] = {g: {c: round(v[0] / v[1] * (2 if c == "FETCH_SIZE" else 1), 1) for c, v in cs.items()} | {"n": max(v[1] for v in cs.values())}
+                          for g, cs in sorted(by_grid.items(), key=lambda kv: -sum(v[0] for v in kv[1].values()))}
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res)[:1500])
