@@ -22,10 +22,12 @@
 
 #include "igemm.h"
 #include <algorithm>
+#include <type_traits>
 
 // DF_TRACE(i): per-workgroup time stamps for tools/dev/igemm_trace.hip (compiles this file with the hook defined); nothing otherwise
 #ifndef DF_TRACE
 #define DF_TRACE(i)
+#define DF_TRACE_WAVE_END(w)
 #endif
 
 namespace df {
@@ -717,7 +719,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   DF_TRACE(2);
 
   // ---- epilogue: accumulators -> LDS (per-wave region) -> 16-byte row segments, one 32-row band of the wave tile at a time (the
-  // single 36 KB buffer holds 4 waves x 32 rows x (WN + 4) floats)
+  // single 36 KB buffer holds 4 waves x 32 rows x (WN + 4) floats).
+  // Next to three workgroups in their main loops a wave gets roughly one VALU issue per MFMA of theirs (tools/dev/igemm_trace.hip:
+  // the epilogue's cycles follow its VALU instruction count, 68 k cycles for ~1000 instructions against 2.6 k alone on the CU), so this
+  // code is written for few vector instructions: stores and residual loads are buffer accesses off descriptors based at the tile's
+  // first row -- the per-pass row offset is a scalar (soffset), the lane part is computed once, rows past M fall outside num_records
+  // and columns past Cout get a poisoned offset: no per-pass address arithmetic, compares or exec masking.
   constexpr int EP_LD = WN + 4;
   static_assert(4 * 32 * EP_LD <= TILE, "epilogue staging must fit the k-tile buffer");
   float *ep = smem + wave * (32 * EP_LD);
@@ -734,54 +741,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   const int valid_rows = p.rows_per_group > 0 ? p.rows_valid - (m0 - grp * p.rows_per_group) : (1 << 30);
   constexpr int BPS = 32 / ERPP;         // passes per 32-row band
+  const int rows_left = min(M - m0, BM);                  // wave-uniform
+  constexpr unsigned POISON = 0x80000000u;                // beyond every num_records below (< 2^31: host-checked)
+  const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out ? p.out + (size_t)m0 * p.out_ld + out_coff : nullptr, 0,
+                                                        p.out ? (unsigned)(((size_t)(rows_left - 1) * p.out_ld + p.Cout) * sizeof(float)) : 0u,
+                                                        0x00020000);
+  const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res ? p.res + (size_t)m0 * p.res_ld + p.res_coff : nullptr), 0,
+                                                        p.res ? (unsigned)(((size_t)(rows_left - 1) * p.res_ld + p.Cout) * sizeof(float)) : 0u,
+                                                        0x00020000);
+  const unsigned vo_out = nok ? (unsigned)(r0 * p.out_ld + n) * 4u : POISON;
+  const unsigned vo_res = nok ? (unsigned)(r0 * p.res_ld + n) * 4u : POISON;
+  const float *ep_rd = ep + r0 * EP_LD + c4;
+  float *ep_wr = ep + 4 * lh * EP_LD + li;
+  // one instantiation per (residual, activation) pair, picked by a scalar branch: the passes carry no selects between variants
+  const int so_out_step = ERPP * p.out_ld * 4, so_res_step = ERPP * p.res_ld * 4;        // scalar byte offsets between passes
+  auto bands = [&](auto has_res, auto act_kind) {
+    constexpr bool HAS_RES = decltype(has_res)::value;
+    constexpr int ACT = decltype(act_kind)::value;
+    int so_out = wm * WM * p.out_ld * 4, so_res = wm * WM * p.res_ld * 4;                 // passes walk the wave tile's rows in order
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) ep[((e & 3) + 8 * (e >> 2) + 4 * lh) * EP_LD + j * 32 + li] = acc[i][j][e];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    f32x4 rres[BPS];
-    if (p.res) {
+        for (int e = 0; e < 16; ++e) ep_wr[((e & 3) + 8 * (e >> 2)) * EP_LD + j * 32] = acc[i][j][e];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      DF_TRACE(8 + 2 * i);
+      const int band = wm * WM + i * 32;                     // first tile row of the band: wave-uniform
+      f32x4 rres[BPS];
+      if constexpr (HAS_RES) {
 #pragma unroll
-      for (int q = 0; q < BPS; ++q) {
-        const int m = m0 + wm * WM + i * 32 + q * ERPP + r0;
-        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-        if (nok && m < M) rv = *reinterpret_cast<const f32x4 *>(p.res + (size_t)m * p.res_ld + p.res_coff + n);
-        rres[q] = rv;
+        for (int q = 0; q < BPS; ++q, so_res += so_res_step)
+          rres[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, vo_res, so_res, 0));
       }
+#pragma unroll
+      for (int q = 0; q < BPS; ++q, so_out += so_out_step) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(ep_rd + q * ERPP * EP_LD);
+        v += bv;
+        if constexpr (HAS_RES) v += rres[q];
+        if constexpr (ACT == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        } else if constexpr (ACT == ACT_PRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+        }
+        if (p.out) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, vo_out, so_out, 0);
+        if (p.colsum) {
+          const bool real = nok && band + q * ERPP + r0 < min(rows_left, valid_rows);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) csum[e] += real ? v[e] : 0.f;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                 // the band is read out before the next one lands in the same rows
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      DF_TRACE(9 + 2 * i);
     }
-#pragma unroll
-    for (int q = 0; q < BPS; ++q) {
-      const int row = i * 32 + q * ERPP + r0;
-      const int m = m0 + wm * WM + row;
-      const bool ok = nok && m < M;
-      f32x4 v = *reinterpret_cast<const f32x4 *>(ep + (q * ERPP + r0) * EP_LD + c4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += bv[e];
-      if (p.res) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += rres[q][e];
-      }
-      if (p.act == ACT_RELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-      } else if (p.act == ACT_PRELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
-      }
-      if (ok && p.out) *reinterpret_cast<f32x4 *>(p.out + (size_t)m * p.out_ld + out_coff + n) = v;
-      if (p.colsum) {
-        const bool real = ok && wm * WM + row < valid_rows;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) csum[e] += real ? v[e] : 0.f;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();                 // the band is read out before the next one lands in the same rows
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  using std::integral_constant;
+  if (p.res) {
+    if (p.act == ACT_RELU) bands(integral_constant<bool, true>{}, integral_constant<int, ACT_RELU>{});
+    else if (p.act == ACT_PRELU) bands(integral_constant<bool, true>{}, integral_constant<int, ACT_PRELU>{});
+    else bands(integral_constant<bool, true>{}, integral_constant<int, ACT_NONE>{});
+  } else {
+    if (p.act == ACT_RELU) bands(integral_constant<bool, false>{}, integral_constant<int, ACT_RELU>{});
+    else if (p.act == ACT_PRELU) bands(integral_constant<bool, false>{}, integral_constant<int, ACT_PRELU>{});
+    else bands(integral_constant<bool, false>{}, integral_constant<int, ACT_NONE>{});
   }
   if (p.colsum) {
     // lanes with equal (lane % LPR) hold different rows of the same 4 columns: fold them (fixed order)
@@ -793,6 +821,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
       *reinterpret_cast<f32x4 *>(p.colsum + ((size_t)z * (gridDim.x / tiles_n) * WAVES_M + (size_t)m_tile * WAVES_M + wm) * p.Cout + n) = csum;
   }
   DF_TRACE(3);
+  DF_TRACE_WAVE_END(wave);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1073,7 +1102,7 @@ bool takes_v4(const ConvParams &p) {
   static const bool force_v1 = getenv("DF_IGEMM_V1") != nullptr;   // dev switch: A/B against the un-pipelined kernel; read once
   const size_t in_bytes = (size_t)p.B * p.H * p.W * p.in_ld * sizeof(float);      // per z slice
   const size_t w_bytes = (size_t)p.Cout * p.KH * p.KW * p.Cin * sizeof(float);
-  return !force_v1 && p.up == 1 && p.H + p.pad < 32768 && p.W + p.pad < 32768 && in_bytes < (1ull << 32) && w_bytes < (1ull << 32) && p.Cout % 4 == 0 && p.out_ld % 4 == 0 &&
+  return !force_v1 && p.up == 1 && p.H + p.pad < 32768 && p.W + p.pad < 32768 && p.out_ld < (1 << 21) && p.res_ld < (1 << 21) && in_bytes < (1ull << 32) && w_bytes < (1ull << 32) && p.Cout % 4 == 0 && p.out_ld % 4 == 0 &&
          p.out_coff % 4 == 0 && p.z_out_coff % 4 == 0 && (!p.res || (p.res_ld % 4 == 0 && p.res_coff % 4 == 0)) &&
          (!p.bias || (p.bias_group_ld % 4 == 0 && p.z_bias % 4 == 0));
 }

@@ -66,8 +66,10 @@ def test_bilinear(case):
     dev = _dev()
     torch.manual_seed(2)
     x = torch.randn(2, h, w, 12, device=dev)
+    # (tolerance: the input gradient sums up to oh*ow = 150 terms per element and torch's backward adds them with atomics in
+    # an order that changes from run to run -- 1.6e-5 apart was seen on the 1x1 -> 10x15 case)
     _pair(lambda t: T.Bilinear.apply(t, oh, ow, align),
-          lambda t: _nhwc(F.interpolate(_nchw(t), size=(oh, ow), mode="bilinear", align_corners=align)), x)
+          lambda t: _nhwc(F.interpolate(_nchw(t), size=(oh, ow), mode="bilinear", align_corners=align)), x, tol=5e-5)
 
 
 def test_logsoftmax_sigmoid_colmean_gather():

@@ -13,6 +13,11 @@ __device__ unsigned long long *df_trace_buf = nullptr;
       if ((i) == 3) r[7] = wall_clock64();                                                                       \
     }                                                                                                            \
   } while (0)
+#define DF_TRACE_WAVE_END(w)                                                                                      \
+  do {                                                                                                           \
+    if ((threadIdx.x & 63) == 0 && df_trace_buf)                                                                 \
+      df_trace_buf[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16 + 12 + (w)] = __builtin_readcyclecounter(); \
+  } while (0)
 #include "../../densefusion_amd/csrc/igemm.hip"
 
 #include <algorithm>
@@ -66,13 +71,67 @@ int main(int argc, char **argv) {
   }
   printf("CUs seen %zu, workgroups %ld; mean cycles: prologue %.0f  main loop %.0f (%.0f / k tile)  epilogue %.0f\n", by_cu.size(), n, pro / n, loop / n,
          loop / n / ((K + 31) / 32), epi / n);
+  {
+    // MFMA-pipe occupancy per CU: every 128x128 workgroup needs nkt * 4096 pipe cycles on each SIMD (64 MFMAs of 64 cycles per k tile)
+    // -- (a) over the CU's whole span, (b) over its middle (first and last workgroup lifetimes cut off: the steady state)
+    const double need = (double)((K + 31) / 32) * 4096.0 * (pick_cfg(p).bm * pick_cfg(p).bn) / 16384.0;
+    double ua = 0, ub = 0, span_max = 0; int nb = 0;
+    for (auto &kv : by_cu) {
+      auto &v = kv.second;
+      unsigned long long s0 = ~0ull, e1 = 0;
+      for (long t : v) { s0 = std::min(s0, h[t * 16]); e1 = std::max(e1, h[t * 16 + 3]); }
+      ua += need * v.size() / (double)(e1 - s0);
+      span_max = std::max(span_max, (double)(e1 - t0));
+      const double life = (pro + loop + epi) / n;
+      const double w0 = s0 + 1.5 * life, w1 = e1 - 1.5 * life;
+      if (w1 > w0 + life) {
+        double work = 0;
+        for (long t : v) {      // the share of the workgroup's main loop that falls inside the window
+          const double a = std::max((double)h[t * 16 + 1], w0), b = std::min((double)h[t * 16 + 2], w1);
+          if (b > a) work += need * (b - a) / (double)(h[t * 16 + 2] - h[t * 16 + 1]);
+        }
+        ub += work / (w1 - w0); ++nb;
+      }
+    }
+    printf("MFMA pipe busy: %.3f over whole CU spans, %.3f in the steady-state window (%d CUs); launch span %.0f cycles\n", ua / by_cu.size(),
+           nb ? ub / nb : 0.0, nb, span_max);
+  }
+  {
+    double d[4] = {0, 0, 0, 0};
+    for (long t = 0; t < tiles; ++t) if (h[t * 16] && h[t * 16 + 8]) {
+      d[0] += h[t*16+8] - h[t*16+2]; d[1] += h[t*16+9] - h[t*16+8];
+      if (h[t*16+10]) { d[2] += h[t*16+10] - h[t*16+9]; d[3] += h[t*16+11] - h[t*16+10]; }
+    }
+    printf("epilogue split (wave 0, mean cycles): band 0 acc->LDS %.0f, read-out + stores %.0f; band 1 acc->LDS %.0f, read-out + stores %.0f\n",
+           d[0] / n, d[1] / n, d[2] / n, d[3] / n);
+  }
+  {
+    // slot turnover: per CU, (span * slots - sum of lifetimes) / workgroups, slots = workgroups that started before the first one ended
+    double gap = 0, skew = 0; long ng = 0, ns = 0;
+    for (auto &kv : by_cu) {
+      auto v = kv.second;
+      std::sort(v.begin(), v.end(), [&](long x, long y) { return h[x * 16] < h[y * 16]; });
+      unsigned long long first_end = ~0ull, e1 = 0; double life = 0;
+      for (long t : v) { first_end = std::min(first_end, h[t * 16 + 3]); e1 = std::max(e1, h[t * 16 + 3]); life += h[t*16+3] - h[t*16]; }
+      int slots = 0;
+      for (long t : v) slots += h[t * 16] < first_end;
+      gap += ((double)(e1 - h[v[0] * 16]) * slots - life); ng += v.size();
+      for (long t : v) if (h[t * 16 + 12]) {
+        unsigned long long lo = ~0ull, hi = 0;
+        for (int w = 0; w < 4; ++w) { lo = std::min(lo, h[t * 16 + 12 + w]); hi = std::max(hi, h[t * 16 + 12 + w]); }
+        skew += hi - lo; ++ns;
+      }
+    }
+    printf("slot turnover: %.0f idle cycles per workgroup (incl. the drain at the end); wave-end skew inside a workgroup %.0f cycles\n", gap / ng,
+           ns ? skew / ns : 0.0);
+  }
   int shown = 0;
   for (auto &kv : by_cu) {
     if (shown++ >= 3) break;
     auto v = kv.second;
     std::sort(v.begin(), v.end(), [&](long x, long y) { return h[x * 16] < h[y * 16]; });
     printf("CU %03x: %zu workgroups; first 8 [start, loop start, loop end, end] in cycles since the first start\n", kv.first, v.size());
-    for (size_t i = 0; i < v.size() && i < 8; ++i)
+    for (size_t i = 0; i < v.size() && i < 12; ++i)
       printf("   wg %6ld  %8llu %8llu %8llu %8llu\n", v[i], h[v[i]*16] - t0, h[v[i]*16+1] - t0, h[v[i]*16+2] - t0, h[v[i]*16+3] - t0);
   }
   return 0;
