@@ -114,6 +114,18 @@ __global__ __launch_bounds__(512) void psp_pool_kernel(const float *__restrict__
       const float *base = in + (size_t)b * H * W * in_ld + in_coff + c;
       f32x4 a4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
       int p = ty;
+      for (; p + 28 < npx; p += 32) {            // eight loads in flight; the additions keep the order of the 4-wide loop below
+        f32x4 v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int q = p + 4 * u, yy = y0 + q / bw, xx = x0 + q % bw;
+          v8[u] = *reinterpret_cast<const f32x4 *>(base + ((size_t)yy * W + xx) * in_ld);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a4[u & 3][e] += v8[u][e];
+      }
       for (; p + 12 < npx; p += 16) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -354,40 +366,60 @@ __global__ __launch_bounds__(TPB) void up3_patch_kernel(const float *__restrict_
 }
 
 // final 1x1 conv 64->32 + LogSoftmax over the 32 channels (lib/pspnet.py:53-56, implicit dim=1) on the up_3 rows
-// z [B*Npad][64].  8 points per workgroup pass: each 32-lane half-wave owns one point, lane = output channel.
+// z [B*Npad][64].  A workgroup takes 64 consecutive points of one object per pass: each 32-lane half-wave owns one point
+// (lane = output channel), 8 rounds; the point-major copy is stored straight away (128 B per point), the channel-major one
+// through an LDS transpose so that its rows go out as 256-byte runs (it was 32 scattered 4-byte stores per point, and the
+// 64 weights per thread were re-loaded for every 8 points: 200 us per step).
+constexpr int LSM_PTS = 64;
 __global__ __launch_bounds__(TPB) void final_lsm_kernel(const float *__restrict__ z, const float *__restrict__ w,
                                                         const float *__restrict__ bias, float *__restrict__ emb,
                                                         float *__restrict__ emb_pm, int B, int N, int Npad) {
+  __shared__ float s_t[32][LSM_PTS + 1];
+  __shared__ __attribute__((aligned(16))) float s_z[LSM_PTS][64];       // the pass's input rows, loaded once with full-width vectors
   const int tid = threadIdx.x;
   const int o = tid & 31, slot = tid >> 5;
   float wr[64];
 #pragma unroll
   for (int c = 0; c < 64; ++c) wr[c] = w[o * 64 + c];
   const float bo = bias[o];
-  const long total = (long)B * N;
-  for (long p0 = (long)blockIdx.x * 8; p0 < total; p0 += (long)gridDim.x * 8) {
-    const long p = p0 + slot;
-    const long b = p < total ? p / N : 0, n = p < total ? p - b * N : 0;
-    const f32x4 *zr = reinterpret_cast<const f32x4 *>(z + ((size_t)b * Npad + n) * 64);     // same address across the half-wave
-    float acc = bo;
+  const int chunks = (N + LSM_PTS - 1) / LSM_PTS;
+  for (long job = blockIdx.x; job < (long)B * chunks; job += gridDim.x) {
+    const int b = (int)(job / chunks), n0 = (int)(job % chunks) * LSM_PTS;
+    {
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(z + ((size_t)b * Npad + n0) * 64);      // rows n0 .. n0+63 < Npad (Npad % 64 == 0)
 #pragma unroll
-    for (int c4 = 0; c4 < 16; ++c4) {
-      const f32x4 zv = zr[c4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_fmaf(zv[e], wr[c4 * 4 + e], acc);
+      for (int v = 0; v < LSM_PTS * 16 / TPB; ++v) reinterpret_cast<f32x4 *>(&s_z[0][0])[tid + v * TPB] = src[tid + v * TPB];
     }
-    float mx = acc;
+    __syncthreads();
+#pragma unroll 2
+    for (int it = 0; it < LSM_PTS / 8; ++it) {
+      const int n = n0 + it * 8 + slot;
+      const bool valid = n < N;
+      const f32x4 *zr = reinterpret_cast<const f32x4 *>(&s_z[it * 8 + slot][0]);                  // same address across the half-wave
+      float acc = bo;
 #pragma unroll
-    for (int d = 16; d >= 1; d >>= 1) { const float t = __shfl_xor(mx, d); mx = t > mx ? t : mx; }
-    const float shf = acc - mx;
-    float se = expf(shf);
+      for (int c4 = 0; c4 < 16; ++c4) {
+        const f32x4 zv = zr[c4];
 #pragma unroll
-    for (int d = 16; d >= 1; d >>= 1) se += __shfl_xor(se, d);
-    const float r = shf - logf(se);
-    if (p < total) {
-      emb[((size_t)b * 32 + o) * N + n] = r;
-      emb_pm[((size_t)b * Npad + n) * 32 + o] = r;
+        for (int e = 0; e < 4; ++e) acc = __builtin_fmaf(zv[e], wr[c4 * 4 + e], acc);
+      }
+      float mx = acc;
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) { const float t = __shfl_xor(mx, d); mx = t > mx ? t : mx; }
+      const float shf = acc - mx;
+      float se = expf(shf);
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) se += __shfl_xor(se, d);
+      const float r = shf - logf(se);
+      if (valid) emb_pm[((size_t)b * Npad + n) * 32 + o] = r;
+      s_t[o][it * 8 + slot] = r;
     }
+    __syncthreads();
+    const int pt = tid & (LSM_PTS - 1);
+    if (n0 + pt < N) {
+      for (int row = tid / LSM_PTS; row < 32; row += TPB / LSM_PTS) emb[((size_t)b * 32 + row) * N + n0 + pt] = s_t[row][pt];
+    }
+    __syncthreads();
   }
 }
 
@@ -570,7 +602,8 @@ void launch_up3_patches(const float *x, const int64_t *choose, float *patch, int
 }
 void launch_final_logsoftmax(const float *z, const float *w, const float *bias, float *emb, float *emb_pm, int B, int N, int Npad,
                              hipStream_t st) {
-  hipLaunchKernelGGL(final_lsm_kernel, dim3(blocks_for((long)B * N * 32)), dim3(TPB), 0, st, z, w, bias, emb, emb_pm, B, N, Npad);
+  const long jobs = (long)B * ((N + LSM_PTS - 1) / LSM_PTS);
+  hipLaunchKernelGGL(final_lsm_kernel, dim3((unsigned)(jobs < 2048 ? (jobs < 1 ? 1 : jobs) : 2048)), dim3(TPB), 0, st, z, w, bias, emb, emb_pm, B, N, Npad);
 }
 void launch_upconv_gather(const float *y, const float *bias, const float *prelu, float *out, int B, int h, int w, int Cout,
                           hipStream_t st) {
