@@ -14,6 +14,6 @@ timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 echo "[profiles] FETCH_SIZE pass done"
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py $SER > gpurun_out/pmc_write.log 2>&1
 echo "[profiles] WRITE_SIZE pass done"
-python3 tools/pmc_summary.py gpurun_out/igemm_traffic.json igemm_f32_v4_kernel gpurun_out/pmc_fetch gpurun_out/pmc_write | cut -c1-400
+python3 tools/pmc_summary.py gpurun_out/igemm_traffic.json igemm_f32_v gpurun_out/pmc_fetch gpurun_out/pmc_write | cut -c1-400
 cp "$(find gpurun_out/prof_bench -name '*kernel_stats.csv' | head -1)" gpurun_out/bench_kernel_stats.csv
 tail -1 gpurun_out/prof_bench.log | cut -c1-300
