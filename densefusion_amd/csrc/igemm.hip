@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
 //   * epilogue through LDS, one 32-row band at a time (the k-tile buffer is reused): global stores / residual loads are
 //     16-byte vectors covering whole 128/256-byte row segments.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int OCC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int OCC, bool PURE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void igemm_f32_v4_kernel(const ConvParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -600,11 +600,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   const int vec = tid % VPR, lrow = tid / VPR;
   // per staged row: (iy0, ix0) of the output pixel's window origin packed as two signed 16-bit halves (H, W < 2^15 - pad:
   // host-checked) -- the register budget of 4 workgroups per CU is exact -- and a_off, the element offset of (b, iy0, ix0, first channel)
+  // PURE (single tap, stride 1, no padding, K % BKT == 0 -- a plain GEMM: row m is pixel m, column k its channel k; 85 % of the
+  // step's GEMM time): the lane part of every load address is fixed and the k tile advances through the instruction's scalar
+  // offset, so the loop carries NO vector arithmetic besides the MFMAs (the general loader spends ~65 VALU instructions per k
+  // tile and wave on tap decode, bounds and selects, as many as it issues MFMAs).  Rows past M / Cout read row 0 instead:
+  // their products only reach outputs that are never stored.
   int a_yx[A_ROWS], a_off[A_ROWS];
 #pragma unroll
   for (int i = 0; i < A_ROWS; ++i) {
     const int m = m0 + lrow + RPP * i;
-    if (m < M) {
+    if constexpr (PURE) {
+      a_yx[i] = 0;
+      a_off[i] = (int)((unsigned)((m < M ? m : 0) * p.in_ld + in_c0 + vec * 4) * 4u);          // bytes
+    } else if (m < M) {
       const int ohw = p.OH * p.OW;
       const int b = fdiv(m, p.ohw_magic, p.ohw_sh, ohw), rem = m - b * ohw;
       const int oy = fdiv(rem, p.ow_magic, p.ow_sh, p.OW), ox = rem - oy * p.OW;
@@ -620,7 +628,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #pragma unroll
   for (int i = 0; i < B_ROWS; ++i) {
     const int n = n0 + lrow + RPP * i;
-    b_off[i] = n < p.Cout ? n * K : -1;
+    if constexpr (PURE) b_off[i] = (int)((unsigned)((n < p.Cout ? n : 0) * K + vec * 4) * 4u);      // bytes
+    else b_off[i] = n < p.Cout ? n * K : -1;
   }
   const bool one_tap = (p.KH * p.KW == 1);
   const int cin_shift = 31 - __builtin_clz(p.Cin);
@@ -633,6 +642,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 
   u32x4 ra[A_ROWS], rb[B_ROWS];
   auto issue_loads = [&](int kt) {
+    if constexpr (PURE) {
+      const int soff = kt * (BK * (int)sizeof(float));      // wave-uniform: the instruction's scalar offset
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (unsigned)a_off[i], soff, 0);
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)b_off[i], soff, 0);
+      return;
+    }
     // the tile index goes through an opaque asm so that the address arithmetic below cannot be strength-reduced
     // into loop-header induction updates: it has to stay here, between the MFMAs, where its issue slots are free
     asm volatile("" : "+s"(kt));
@@ -1207,12 +1224,18 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
       hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2, 32>), grid, dim3(256), (size_t)2 * 128 * 36 * sizeof(float), st, pl);
   } else if (takes_v4(p)) {
     // workgroups per CU: 4 / 5 / 6 (the register budget amdgpu_waves_per_eu leaves each: 128 / 102 / 85 VGPRs + AGPRs)
-    if (c.bm == 128 && c.bn == 128)
-      hipLaunchKernelGGL((igemm_f32_v4_kernel<128, 128, 2, 2, 32, 4>), grid, dim3(256), 256 * ROW, st, pl);
-    else if (c.bm == 128)
-      hipLaunchKernelGGL((igemm_f32_v4_kernel<128, 64, 2, 2, 32, 5>), grid, dim3(256), 192 * ROW, st, pl);
-    else      // (a BK = 64 form of the small tile was measured: 0.85-1.0x, dropped)
-      hipLaunchKernelGGL((igemm_f32_v4_kernel<64, 64, 2, 2, 32, 6>), grid, dim3(256), 128 * ROW, st, pl);
+    static const bool no_pure = getenv("DF_IGEMM_NOPURE") != nullptr;      // dev switch: the general loader for every launch; read once
+    const bool pure = !no_pure && p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0 && (p.Cin % 32) == 0;
+    if (c.bm == 128 && c.bn == 128) {
+      if (pure) hipLaunchKernelGGL((igemm_f32_v4_kernel<128, 128, 2, 2, 32, 4, true>), grid, dim3(256), 256 * ROW, st, pl);
+      else hipLaunchKernelGGL((igemm_f32_v4_kernel<128, 128, 2, 2, 32, 4, false>), grid, dim3(256), 256 * ROW, st, pl);
+    } else if (c.bm == 128) {
+      if (pure) hipLaunchKernelGGL((igemm_f32_v4_kernel<128, 64, 2, 2, 32, 5, true>), grid, dim3(256), 192 * ROW, st, pl);
+      else hipLaunchKernelGGL((igemm_f32_v4_kernel<128, 64, 2, 2, 32, 5, false>), grid, dim3(256), 192 * ROW, st, pl);
+    } else {      // (a BK = 64 form of the small tile was measured: 0.85-1.0x, dropped)
+      if (pure) hipLaunchKernelGGL((igemm_f32_v4_kernel<64, 64, 2, 2, 32, 6, true>), grid, dim3(256), 128 * ROW, st, pl);
+      else hipLaunchKernelGGL((igemm_f32_v4_kernel<64, 64, 2, 2, 32, 6, false>), grid, dim3(256), 128 * ROW, st, pl);
+    }
   } else if (c.bm == 128) {
     hipLaunchKernelGGL((igemm_f32_kernel<128, 128, 2, 2>), grid, dim3(256), (size_t)2 * 256 * LDK * sizeof(float), st, p);
   } else {
