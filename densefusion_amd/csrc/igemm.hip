@@ -543,8 +543,10 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
 //   * epilogue through LDS, one 32-row band at a time (the k-tile buffer is reused): global stores / residual loads are
 //     16-byte vectors covering whole 128/256-byte row segments.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int OCC, bool PURE>
+// LOADER: 0 general (any geometry, K tail), 1 plain GEMM, 2 multi-tap with Cin a power of two >= BKT (a k tile lies inside one tap)
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int OCC, int LOADER>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void igemm_f32_v4_kernel(const ConvParams p) {
+  constexpr bool PURE = LOADER == 1, TAPU = LOADER == 2;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -591,8 +593,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 
   // buffer descriptors (wave-uniform): reads past num_records return 0
   // (one descriptor per z slice: a z-batched launch may span more than the 4 GB a descriptor can address)
-  const unsigned in_bytes = (unsigned)((size_t)p.B * p.H * p.W * p.in_ld * sizeof(float));
-  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in + (size_t)z * p.z_in_coff), 0, in_bytes, 0x00020000);
+  // (TAPU: the descriptor starts `in_shift` elements BEFORE the tensor, so that the offset of a window origin in the padding above /
+  // left of the image is non-negative; nothing is ever read there -- such taps are masked)
+  const int in_shift = TAPU ? (p.pad * p.W + p.pad) * p.in_ld : 0;
+  const unsigned in_bytes = (unsigned)(((size_t)p.B * p.H * p.W * p.in_ld + in_shift) * sizeof(float));
+  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in + (size_t)z * p.z_in_coff) - in_shift, 0, in_bytes, 0x00020000);
   const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wgt + (size_t)z * p.z_wgt), 0,
                                                       (unsigned)((size_t)p.Cout * K * sizeof(float)), 0x00020000);
   const int in_c0 = p.in_coff;
@@ -612,6 +617,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     if constexpr (PURE) {
       a_yx[i] = 0;
       a_off[i] = (int)((unsigned)((m < M ? m : 0) * p.in_ld + in_c0 + vec * 4) * 4u);          // bytes
+    } else if constexpr (TAPU) {
+      // a_yx: bit t set <=> tap t of this row's window lies inside the image (all clear for rows past M);
+      // a_off: byte offset of (b, iy0, ix0, first channel + this lane's vector) from the shifted descriptor base
+      unsigned mask = 0;
+      int off = 0;
+      if (m < M) {
+        const int ohw = p.OH * p.OW;
+        const int b = fdiv(m, p.ohw_magic, p.ohw_sh, ohw), rem = m - b * ohw;
+        const int oy = fdiv(rem, p.ow_magic, p.ow_sh, p.OW), ox = rem - oy * p.OW;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        unsigned cols = 0;
+        for (int kx = 0; kx < p.KW; ++kx) cols |= (unsigned)((unsigned)(ix0 + kx * p.dil) < (unsigned)p.W) << kx;
+        for (int ky = 0; ky < p.KH; ++ky) mask |= ((unsigned)(iy0 + ky * p.dil) < (unsigned)p.H) ? cols << (ky * p.KW) : 0u;
+        off = (((b * p.H + iy0) * p.W + ix0) * p.in_ld + in_shift + in_c0 + vec * 4) * 4;
+      }
+      a_yx[i] = (int)mask;
+      a_off[i] = off;
     } else if (m < M) {
       const int ohw = p.OH * p.OW;
       const int b = fdiv(m, p.ohw_magic, p.ohw_sh, ohw), rem = m - b * ohw;
@@ -628,7 +650,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #pragma unroll
   for (int i = 0; i < B_ROWS; ++i) {
     const int n = n0 + lrow + RPP * i;
-    if constexpr (PURE) b_off[i] = (int)((unsigned)((n < p.Cout ? n : 0) * K + vec * 4) * 4u);      // bytes
+    if constexpr (PURE || TAPU) b_off[i] = (int)((unsigned)((n < p.Cout ? n : 0) * K + vec * 4) * 4u);      // bytes
     else b_off[i] = n < p.Cout ? n * K : -1;
   }
   const bool one_tap = (p.KH * p.KW == 1);
@@ -648,6 +670,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
       for (int i = 0; i < A_ROWS; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (unsigned)a_off[i], soff, 0);
 #pragma unroll
       for (int i = 0; i < B_ROWS; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)b_off[i], soff, 0);
+      return;
+    }
+    if constexpr (TAPU) {
+      // the whole k tile belongs to one tap: tap, its (dy, dx) displacement and the channel base are scalars and travel in the
+      // instruction's scalar offset; per row one bit test selects the fixed lane offset or an out-of-range one (-> zeros)
+      const int k0 = kt * BK;
+      const int tap = k0 >> cin_shift;
+      const int ky = (tap * kw_magic) >> 16, kx = tap - ky * p.KW;
+      const int soff = (((ky * p.W + kx) * p.dil) * p.in_ld + (k0 & (p.Cin - 1))) * (int)sizeof(float);
+      const unsigned bit = k0 < K ? 1u << tap : 0u;      // (0: the prefetch one tile past the end)
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        unsigned off = ((unsigned)a_yx[i] & bit) ? (unsigned)a_off[i] : 0x80000000u;      // num_records < 2^31: host-checked
+        asm("" : "+v"(off));      // opaque: keeps hipcc from turning the select into two branchy loads
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, soff, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)b_off[i], k0 * (int)sizeof(float), 0);
       return;
     }
     // the tile index goes through an opaque asm so that the address arithmetic below cannot be strength-reduced
@@ -1225,17 +1265,22 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
   } else if (takes_v4(p)) {
     // workgroups per CU: 4 / 5 / 6 (the register budget amdgpu_waves_per_eu leaves each: 128 / 102 / 85 VGPRs + AGPRs)
     static const bool no_pure = getenv("DF_IGEMM_NOPURE") != nullptr;      // dev switch: the general loader for every launch; read once
-    const bool pure = !no_pure && p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0 && (p.Cin % 32) == 0;
-    if (c.bm == 128 && c.bn == 128) {
-      if (pure) hipLaunchKernelGGL((igemm_f32_v4_kernel<128, 128, 2, 2, 32, 4, true>), grid, dim3(256), 256 * ROW, st, pl);
-      else hipLaunchKernelGGL((igemm_f32_v4_kernel<128, 128, 2, 2, 32, 4, false>), grid, dim3(256), 256 * ROW, st, pl);
-    } else if (c.bm == 128) {
-      if (pure) hipLaunchKernelGGL((igemm_f32_v4_kernel<128, 64, 2, 2, 32, 5, true>), grid, dim3(256), 192 * ROW, st, pl);
-      else hipLaunchKernelGGL((igemm_f32_v4_kernel<128, 64, 2, 2, 32, 5, false>), grid, dim3(256), 192 * ROW, st, pl);
-    } else {      // (a BK = 64 form of the small tile was measured: 0.85-1.0x, dropped)
-      if (pure) hipLaunchKernelGGL((igemm_f32_v4_kernel<64, 64, 2, 2, 32, 6, true>), grid, dim3(256), 128 * ROW, st, pl);
-      else hipLaunchKernelGGL((igemm_f32_v4_kernel<64, 64, 2, 2, 32, 6, false>), grid, dim3(256), 128 * ROW, st, pl);
-    }
+    const int taps = p.KH * p.KW;
+    const size_t shifted = ((size_t)p.B * p.H * p.W + (size_t)p.pad * p.W + p.pad) * p.in_ld * sizeof(float);
+    // loader 1: plain GEMM; loader 2: several taps, every 32-wide k tile inside one tap, tap mask in 32 bits, offsets below 2^31
+    const int loader = no_pure ? 0
+                       : taps == 1 && p.stride == 1 && p.pad == 0 && p.Cin % 32 == 0 ? 1
+                       : taps > 1 && taps <= 32 && p.Cin >= 32 && shifted < (1ull << 31) ? 2 : 0;     // (Cin is a power of two here)
+    auto launch = [&](auto bm, auto bn, auto occ, size_t rows) {
+      constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value, OCC_ = decltype(occ)::value;
+      if (loader == 1) hipLaunchKernelGGL((igemm_f32_v4_kernel<BM_, BN_, 2, 2, 32, OCC_, 1>), grid, dim3(256), rows * ROW, st, pl);
+      else if (loader == 2) hipLaunchKernelGGL((igemm_f32_v4_kernel<BM_, BN_, 2, 2, 32, OCC_, 2>), grid, dim3(256), rows * ROW, st, pl);
+      else hipLaunchKernelGGL((igemm_f32_v4_kernel<BM_, BN_, 2, 2, 32, OCC_, 0>), grid, dim3(256), rows * ROW, st, pl);
+    };
+    using std::integral_constant;
+    if (c.bm == 128 && c.bn == 128) launch(integral_constant<int, 128>{}, integral_constant<int, 128>{}, integral_constant<int, 4>{}, 256);
+    else if (c.bm == 128) launch(integral_constant<int, 128>{}, integral_constant<int, 64>{}, integral_constant<int, 5>{}, 192);
+    else launch(integral_constant<int, 64>{}, integral_constant<int, 64>{}, integral_constant<int, 6>{}, 128);      // (a BK = 64 form of the small tile was measured: 0.85-1.0x, dropped)
   } else if (c.bm == 128) {
     hipLaunchKernelGGL((igemm_f32_kernel<128, 128, 2, 2>), grid, dim3(256), (size_t)2 * 256 * LDK * sizeof(float), st, p);
   } else {
