@@ -763,7 +763,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   DF_TRACE(1);
   for (int kt = 0; kt < nkt; ++kt) {
     write_lds();                         // tile kt: registers -> LDS (waits for its loads)
-    issue_loads(kt + 1);                 // tile kt+1 flies while tile kt multiplies (zeros past the end)
+    // tile kt+1 flies while tile kt multiplies.  Past the end the general loader's offsets are out of range (zeros, no traffic);
+    // the scalar-offset loaders would fetch the next 128 bytes of every row (+6 % reads at K = 512, +17 % at K = 192): skipped
+    if (LOADER == 0 || kt + 1 < nkt) issue_loads(kt + 1);
     __syncthreads();
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) {
