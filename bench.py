@@ -482,7 +482,7 @@ def main():
                     help="split the step's objects into this many multi-bucket calls, one HIP stream each (0: one call per crop size, "
                          "the round-1 launch structure)")
     ap.add_argument("--no-streams", action="store_true", help="run the groups back to back on one stream")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("DF_BENCH_INFLIGHT", "3")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("DF_BENCH_INFLIGHT", "4")),
                     help="steps in flight: consecutive steps (independent batches of the frame stream) alternate between this many "
                          "instances (own workspaces, output buffers, stream, hipGraph), so one step's memory-bound kernels overlap "
                          "the next step's GEMMs")
