@@ -198,3 +198,33 @@ def test_v1_kernel_paths(geom):
     _lib.check(_lib.lib().df_conv2d_dgrad_nhwc(ctypes.byref(dsc), dy.contiguous().data_ptr(), dx.data_ptr(), scratch.data_ptr(), 0,
                                                 _lib.current_stream()), "conv2d_dgrad")
     assert (dx - xr.grad).abs().max() < 2e-5 * max(1.0, float(xr.grad.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [
+    # (B, H, W, Cin, Cout, k, pad): row counts that end inside a 128-row tile, for the plain-GEMM, tap-uniform and general loaders,
+    # with column counts that end inside a column tile
+    (1, 25, 30, 64, 128, 1, 0), (3, 17, 19, 256, 576, 1, 0), (2, 15, 15, 64, 64, 3, 1), (1, 9, 11, 32, 192, 3, 1), (2, 13, 7, 4, 64, 7, 3),
+    (5, 100, 37, 64, 320, 1, 0),
+])
+def test_conv_writes_nothing_outside_its_output(geom):
+    """The epilogue drops rows past M and columns past Cout through the buffer descriptor's range (voffset + soffset against
+    num_records -- tools/dev/soffset_check.hip shows the sum is what the hardware checks): the output is a window of a larger
+    tensor filled with a sentinel, which must survive around it."""
+    from densefusion_amd.ops import conv2d_nhwc
+    B, H, W, Cin, Cout, k, pad = geom
+    dev = torch.device("cuda:0")
+    torch.manual_seed(sum(geom))
+    x = torch.randn(B, H, W, Cin, device=dev)
+    w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05
+    ld, coff, guard_rows = Cout + 8, 4, 160
+    rows = B * H * W
+    big = torch.full((rows + guard_rows, ld), 7.25, device=dev)
+    out = big[:rows].view(B, H, W, ld)
+    conv2d_nhwc(x, w, None, stride=1, pad=pad, act=1, out=out, out_coff=coff)
+    torch.cuda.synchronize()
+    assert bool((big[rows:] == 7.25).all()), "rows past M were written"
+    assert bool((big[:rows, :coff] == 7.25).all()) and bool((big[:rows, coff + Cout:] == 7.25).all()), "columns outside the channel window were written"
+    want = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), None, 1, pad)).permute(0, 2, 3, 1)
+    got = out[..., coff:coff + Cout].double()
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
