@@ -228,3 +228,46 @@ def test_conv_writes_nothing_outside_its_output(geom):
     want = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), None, 1, pad)).permute(0, 2, 3, 1)
     got = out[..., coff:coff + Cout].double()
     assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+_LOADER_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from densefusion_amd.ops import conv2d_nhwc
+dev = torch.device("cuda:0")
+outs = []
+for i, (B, H, W, Cin, Cout, k, stride, pad, dil) in enumerate([
+        (40, 32, 32, 64, 128, 1, 1, 0, 1),      # plain GEMM (single tap), full grid
+        (16, 40, 40, 64, 64, 3, 1, 1, 1),       # tap-uniform loader, 3x3
+        (16, 40, 40, 64, 128, 3, 2, 1, 1),      # tap-uniform, stride 2
+        (8, 20, 20, 256, 512, 3, 1, 4, 4),      # tap-uniform, dilation 4
+        (3, 9, 11, 32, 64, 3, 1, 1, 1)]):       # small grid (software-pipelined kernel either way)
+    torch.manual_seed(100 + i)
+    x = torch.randn(B, H, W, Cin, device=dev)
+    w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05
+    b = torch.randn(Cout, device=dev)
+    outs.append(conv2d_nhwc(x, w, b, stride=stride, pad=pad, dil=dil, act=1).cpu())
+torch.save(outs, sys.argv[2])
+"""
+
+
+@pytest.mark.gpu
+def test_specialised_loaders_are_bit_identical_to_the_general_one(tmp_path):
+    """The plain-GEMM and tap-uniform loaders only change HOW a k tile's addresses are formed: every output element still adds the
+    same products in the same order, so results must equal the general loader's bit for bit (two child processes: the dev
+    switch DF_IGEMM_NOPURE is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = []
+    for tag, env in (("special", {}), ("general", {"DF_IGEMM_NOPURE": "1"})):
+        f = str(tmp_path / f"{tag}.pt")
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, "-c", _LOADER_SCRIPT, root, f], check=True, env=e, timeout=300)
+        files.append(f)
+    a, b = torch.load(files[0]), torch.load(files[1])
+    assert len(a) == len(b) == 5
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), f"case {i}: loaders disagree, max diff {float((u - v).abs().max())}"
