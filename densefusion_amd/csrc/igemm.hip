@@ -46,6 +46,14 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int sh, int d) {
   return d == 1 ? n : (int)(__umulhi((unsigned)n, magic) >> sh);
 }
 
+// 16-byte non-temporal buffer store with a SCALAR offset, followed by one wait state.  gfx950 hazard (tools/dev/b128_war_check.hip):
+// a vector instruction that overwrites the data registers of a 128-bit buffer store in the very next issue slot can corrupt the last
+// dword of lanes 12-15 of each row of 16 when the memory pipeline is busy; hipcc inserts the wait state itself only when the store has
+// no scalar offset register.  Store and s_nop are one asm statement, so nothing can be scheduled between them.
+__device__ __forceinline__ void buffer_store_b128_nt(u32x4 data, __amdgpu_buffer_rsrc_t rs, unsigned voffset, int soffset) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 0" : : "v"(data), "v"(voffset), "s"(rs), "s"(soffset) : "memory");
+}
+
 // magic = ceil(2^(31+L) / d) with 2^(L-1) < d <= 2^L: exact for every n < 2^31 (error term n * (magic*d - 2^(31+L)) < 2^(31+L))
 void make_fdiv(long d, unsigned &magic, int &sh) {
   magic = 0; sh = 0;
@@ -544,7 +552,9 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
 //     16-byte vectors covering whole 128/256-byte row segments.
 // ------------------------------------------------------------------------------------------------
 // LOADER: 0 general (any geometry, K tail), 1 plain GEMM, 2 multi-tap with Cin a power of two >= BKT (a k tile lies inside one tap)
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int OCC, int LOADER>
+// COLSUM: the launches with a fused column sum (p.colsum; p.out may be null) -- their own instantiation, so that the others carry no
+// per-pass tests for it.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int OCC, int LOADER, bool COLSUM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void igemm_f32_v4_kernel(const ConvParams p) {
   constexpr bool PURE = LOADER == 1, TAPU = LOADER == 2;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -755,8 +765,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][e], a[i][e], acc[i][j], 0, 0, 0);
   };
+  // (operands swapped: the MFMA computes the TRANSPOSED 32x32 block, so lane (li, lh) ends up holding, for row li of the block, the
+  // columns 8q + 4lh .. +3 in acc[4q .. 4q+3] -- four consecutive output channels of one pixel: the epilogue stages a band with 8
+  // ds_write_b128 per lane instead of 32 ds_write2_b32.  Same products, same order per output element.)
 
   DF_TRACE(0);
   issue_loads(0);
@@ -804,7 +817,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   // output stores carry the non-temporal hint: a tile's 64 KB of results are not read again by this launch, and without the hint
   // they push the A rows that sibling column tiles are about to re-read out of the 4 MB L2 (counter reads -4 % over the step's
   // launches, -21 % on the Winograd-domain GEMMs; 34.9 -> 34.4 ms of GEMM time per step)
-  constexpr int STORE_NT = 2;
   constexpr unsigned POISON = 0x80000000u;                // beyond every num_records below (< 2^31: host-checked)
   const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out ? p.out + (size_t)m0 * p.out_ld + out_coff : nullptr, 0,
                                                         p.out ? (unsigned)(((size_t)(rows_left - 1) * p.out_ld + p.Cout) * sizeof(float)) : 0u,
@@ -815,7 +827,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   const unsigned vo_out = nok ? (unsigned)(r0 * p.out_ld + n) * 4u : POISON;
   const unsigned vo_res = nok ? (unsigned)(r0 * p.res_ld + n) * 4u : POISON;
   const float *ep_rd = ep + r0 * EP_LD + c4;
-  float *ep_wr = ep + 4 * lh * EP_LD + li;
+  float *ep_wr = ep + li * EP_LD + 4 * lh;
   // one instantiation per (residual, activation) pair, picked by a scalar branch: the passes carry no selects between variants
   const int so_out_step = ERPP * p.out_ld * 4, so_res_step = ERPP * p.res_ld * 4;        // scalar byte offsets between passes
   auto bands = [&](auto has_res, auto act_kind) {
@@ -827,7 +839,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) ep_wr[((e & 3) + 8 * (e >> 2)) * EP_LD + j * 32] = acc[i][j][e];
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4 *>(ep_wr + j * 32 + 8 * q) = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -851,8 +864,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
         }
-        if (p.out) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, vo_out, so_out, STORE_NT);
-        if (p.colsum) {
+        if (!COLSUM || p.out) buffer_store_b128_nt(__builtin_bit_cast(u32x4, v), rs_out, vo_out, so_out);
+        if constexpr (COLSUM) {
           const bool real = nok && band + q * ERPP + r0 < min(rows_left, valid_rows);
 #pragma unroll
           for (int e = 0; e < 4; ++e) csum[e] += real ? v[e] : 0.f;
@@ -865,7 +878,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     }
   };
   using std::integral_constant;
-  if (p.res) {
+  if (!COLSUM && p.res) {      // (a column-sum launch never carries a residual: host-checked)
     if (p.act == ACT_RELU) bands(integral_constant<bool, true>{}, integral_constant<int, ACT_RELU>{});
     else if (p.act == ACT_PRELU) bands(integral_constant<bool, true>{}, integral_constant<int, ACT_PRELU>{});
     else bands(integral_constant<bool, true>{}, integral_constant<int, ACT_NONE>{});
@@ -874,7 +887,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     else if (p.act == ACT_PRELU) bands(integral_constant<bool, false>{}, integral_constant<int, ACT_PRELU>{});
     else bands(integral_constant<bool, false>{}, integral_constant<int, ACT_NONE>{});
   }
-  if (p.colsum) {
+  if constexpr (COLSUM) {
     // lanes with equal (lane % LPR) hold different rows of the same 4 columns: fold them (fixed order)
 #pragma unroll
     for (int d = 32; d >= LPR; d >>= 1)
@@ -1275,12 +1288,16 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
                        : taps > 1 && taps <= 32 && p.Cin >= 32 && shifted < (1ull << 31) ? 2 : 0;     // (Cin is a power of two here)
     auto launch = [&](auto bm, auto bn, auto occ, size_t rows) {
       constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value, OCC_ = decltype(occ)::value;
-      if (loader == 1) hipLaunchKernelGGL((igemm_f32_v4_kernel<BM_, BN_, 2, 2, 32, OCC_, 1>), grid, dim3(256), rows * ROW, st, pl);
-      else if (loader == 2) hipLaunchKernelGGL((igemm_f32_v4_kernel<BM_, BN_, 2, 2, 32, OCC_, 2>), grid, dim3(256), rows * ROW, st, pl);
-      else hipLaunchKernelGGL((igemm_f32_v4_kernel<BM_, BN_, 2, 2, 32, OCC_, 0>), grid, dim3(256), rows * ROW, st, pl);
+      if (loader == 1) hipLaunchKernelGGL((igemm_f32_v4_kernel<BM_, BN_, 2, 2, 32, OCC_, 1, false>), grid, dim3(256), rows * ROW, st, pl);
+      else if (loader == 2) hipLaunchKernelGGL((igemm_f32_v4_kernel<BM_, BN_, 2, 2, 32, OCC_, 2, false>), grid, dim3(256), rows * ROW, st, pl);
+      else hipLaunchKernelGGL((igemm_f32_v4_kernel<BM_, BN_, 2, 2, 32, OCC_, 0, false>), grid, dim3(256), rows * ROW, st, pl);
     };
     using std::integral_constant;
-    if (c.bm == 128 && c.bn == 128) launch(integral_constant<int, 128>{}, integral_constant<int, 128>{}, integral_constant<int, 4>{}, 256);
+    if (p.colsum && p.res) return set_error(DF_ERR_ARG, "conv: a column-sum launch cannot take a residual");
+    if (p.colsum) {      // always the 128x128 tile (pick_cfg); the per-point launches that use it are plain GEMMs
+      if (loader == 1) hipLaunchKernelGGL((igemm_f32_v4_kernel<128, 128, 2, 2, 32, 4, 1, true>), grid, dim3(256), 256 * ROW, st, pl);
+      else hipLaunchKernelGGL((igemm_f32_v4_kernel<128, 128, 2, 2, 32, 4, 0, true>), grid, dim3(256), 256 * ROW, st, pl);
+    } else if (c.bm == 128 && c.bn == 128) launch(integral_constant<int, 128>{}, integral_constant<int, 128>{}, integral_constant<int, 4>{}, 256);
     else if (c.bm == 128) launch(integral_constant<int, 128>{}, integral_constant<int, 64>{}, integral_constant<int, 5>{}, 192);
     else launch(integral_constant<int, 64>{}, integral_constant<int, 64>{}, integral_constant<int, 6>{}, 128);      // (a BK = 64 form of the small tile was measured: 0.85-1.0x, dropped)
   } else if (c.bm == 128) {
