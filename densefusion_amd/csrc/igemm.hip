@@ -752,20 +752,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   };
 
   f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  auto mfma_group = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
+  // FIRST: the group's first MFMA of every block takes the instruction's literal-zero C operand instead of the accumulator: the first k
+  // tile is peeled below, so the 64 v_mov that would clear the accumulators are never issued (every vector instruction a workgroup
+  // spends outside its MFMAs is issue time the SIMD's other waves cannot use for theirs: tools/dev/mfma_coissue.hip)
+  auto mfma_group = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN], auto first) {
+    constexpr bool FIRST = decltype(first)::value;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (FIRST) {
+            if (e == 0) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][e], a[i][e], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+              continue;
+            }
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][e], a[i][e], acc[i][j], 0, 0, 0);
+        }
   };
   // (operands swapped: the MFMA computes the TRANSPOSED 32x32 block, so lane (li, lh) ends up holding, for row li of the block, the
   // columns 8q + 4lh .. +3 in acc[4q .. 4q+3] -- four consecutive output channels of one pixel: the epilogue stages a band with 8
@@ -774,7 +779,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   DF_TRACE(0);
   issue_loads(0);
   DF_TRACE(1);
-  for (int kt = 0; kt < nkt; ++kt) {
+  using std::integral_constant;
+  auto k_tile = [&](int kt, auto first) {
+    constexpr bool FIRST = decltype(first)::value;
     write_lds();                         // tile kt: registers -> LDS (waits for its loads)
     // tile kt+1 flies while tile kt multiplies.  Past the end the general loader's offsets are out of range (zeros, no traffic);
     // the scalar-offset loaders would fetch the next 128 bytes of every row (+6 % reads at K = 512, +17 % at K = 192): skipped
@@ -783,11 +790,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) {
       read_frags(pp, a0, b0);
-      mfma_group(a0[0], b0[0]);
-      mfma_group(a0[1], b0[1]);
+      if (FIRST && pp == 0) mfma_group(a0[0], b0[0], integral_constant<bool, true>{});
+      else mfma_group(a0[0], b0[0], integral_constant<bool, false>{});
+      mfma_group(a0[1], b0[1], integral_constant<bool, false>{});
     }
     __syncthreads();                     // every wave has read tile kt before tile kt+1 overwrites it
-  }
+  };
+  k_tile(0, integral_constant<bool, true>{});          // (K >= 1: there is always a first tile)
+  for (int kt = 1; kt < nkt; ++kt) k_tile(kt, integral_constant<bool, false>{});
   DF_TRACE(2);
 
   // ---- epilogue: accumulators -> LDS (per-wave region) -> 16-byte row segments, one 32-row band of the wave tile at a time (the
@@ -877,7 +887,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
       DF_TRACE(9 + 2 * i);
     }
   };
-  using std::integral_constant;
   if (!COLSUM && p.res) {      // (a column-sum launch never carries a residual: host-checked)
     if (p.act == ACT_RELU) bands(integral_constant<bool, true>{}, integral_constant<int, ACT_RELU>{});
     else if (p.act == ACT_PRELU) bands(integral_constant<bool, true>{}, integral_constant<int, ACT_PRELU>{});
