@@ -34,6 +34,11 @@ struct ConvParams {
   int ngroup = 0;   // column tiles per L2-resident weight group (0 = one group); set by launch_conv
   long z_in_coff = 0, z_wgt = 0, z_bias = 0, z_out_coff = 0;
   // magic pairs for the kernels' divisions by OH*OW and OW (set by the launchers)
+  // tile decode of the v4 kernel without integer divisions (set by launch_conv): row-tile count, tiles per full weight group, and
+  // division magics (make_fdiv) for the group size, the widths of a full / the last group and rows_per_group
+  int tiles_m = 0, tile_gn = 0, tile_full = 0;
+  unsigned full_magic = 0, gn_magic = 0, gl_magic = 0, rpg_magic = 0;
+  int full_sh = 0, gn_sh = 0, gl_sh = 0, rpg_sh = 0;
   unsigned ohw_magic = 0, ow_magic = 0;
   int ohw_sh = 0, ow_sh = 0;
 };

@@ -587,14 +587,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   // column-tile groups: when the weight operand is too big for an XCD's L2 (4 MB), the tiles are walked group by group
   // (p.ngroup column tiles, all row blocks, next group ...) so that the group's weight slice stays L2-resident while the
   // activation rows stream through once per group instead of every column tile missing on both operands
+  // (divisions by host-made magics: the prologue is issue time the SIMD's other waves lose)
   int n_tile, m_tile;
+  const int tiles_m = p.tiles_m;
   {
-    const int GN = p.ngroup > 0 && p.ngroup < tiles_n ? p.ngroup : tiles_n;
-    const int tiles_m = (int)(gridDim.x / tiles_n);
-    const int full = tiles_m * GN;
-    const int g = wgid / full, rem = wgid - g * full;
+    const int GN = p.tile_gn, full = p.tile_full;
+    const int g = fdiv(wgid, p.full_magic, p.full_sh, full), rem = wgid - g * full;
     const int gw = min(GN, tiles_n - g * GN);
-    m_tile = rem / gw;
+    m_tile = gw == GN ? fdiv(rem, p.gn_magic, p.gn_sh, GN) : fdiv(rem, p.gl_magic, p.gl_sh, gw);
     n_tile = g * GN + (rem - m_tile * gw);
   }
   const int m0 = m_tile * BM, n0 = n_tile * BN;
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   static_assert(4 * 32 * EP_LD <= TILE, "epilogue staging must fit the k-tile buffer");
   float *ep = smem + wave * (32 * EP_LD);
   const float slope = (p.act == ACT_PRELU) ? p.prelu[0] : 0.f;
-  const int grp = (p.rows_per_group > 0) ? m0 / p.rows_per_group : 0;
+  const int grp = (p.rows_per_group > 0) ? fdiv(m0, p.rpg_magic, p.rpg_sh, p.rows_per_group) : 0;
   const float *bias = p.bias ? p.bias + z * p.z_bias + (p.bias_group_ld > 0 ? (size_t)grp * p.bias_group_ld : 0) : nullptr;
   constexpr int LPR = WN / 4;            // lanes per row
   constexpr int ERPP = 64 / LPR;         // rows per pass
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #pragma unroll
       for (int e = 0; e < 4; ++e) csum[e] += __shfl_xor(csum[e], d);
     if (lane < LPR && nok)
-      *reinterpret_cast<f32x4 *>(p.colsum + ((size_t)z * (gridDim.x / tiles_n) * WAVES_M + (size_t)m_tile * WAVES_M + wm) * p.Cout + n) = csum;
+      *reinterpret_cast<f32x4 *>(p.colsum + ((size_t)z * tiles_m * WAVES_M + (size_t)m_tile * WAVES_M + wm) * p.Cout + n) = csum;
   }
   DF_TRACE(3);
   DF_TRACE_WAVE_END(wave);
@@ -1254,12 +1254,24 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
   ConvParams pl = p;       // launch copy: + the column-tile group width and the division magics
   make_fdiv((long)p.OH * p.OW, pl.ohw_magic, pl.ohw_sh);
   make_fdiv(p.OW, pl.ow_magic, pl.ow_sh);
+  auto set_tile_decode = [&]() {      // after ngroup is known
+    const int tiles_n = (p.Cout + c.bn - 1) / c.bn;
+    pl.tiles_m = (int)((M + c.bm - 1) / c.bm);
+    pl.tile_gn = pl.ngroup > 0 && pl.ngroup < tiles_n ? pl.ngroup : tiles_n;
+    pl.tile_full = pl.tiles_m * pl.tile_gn;
+    const int last = tiles_n % pl.tile_gn;
+    make_fdiv(pl.tile_full, pl.full_magic, pl.full_sh);
+    make_fdiv(pl.tile_gn, pl.gn_magic, pl.gn_sh);
+    make_fdiv(last ? last : pl.tile_gn, pl.gl_magic, pl.gl_sh);
+    make_fdiv(p.rows_per_group > 0 ? p.rows_per_group : 1, pl.rpg_magic, pl.rpg_sh);
+  };
   {
     const size_t slice = (size_t)c.bn * p.KH * p.KW * p.Cin * sizeof(float);       // weights of one column tile
     const long tn = (p.Cout + c.bn - 1) / c.bn;
     static const long budget = getenv("DF_IGEMM_WGROUP_KB") ? atol(getenv("DF_IGEMM_WGROUP_KB")) * 1024L : 3L << 20;
     if (budget > 0 && (size_t)tn * slice > (size_t)budget) pl.ngroup = (int)std::max<long>(1, budget / (long)slice);
   }
+  set_tile_decode();
   if (p.rows_per_group > 0 && (p.rows_per_group % c.bm))
     return set_error(DF_ERR_ARG, "conv: rows_per_group must be a multiple of %d", c.bm);
   const long tiles = ((M + c.bm - 1) / c.bm) * ((p.Cout + c.bn - 1) / c.bn);
