@@ -46,12 +46,13 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int sh, int d) {
   return d == 1 ? n : (int)(__umulhi((unsigned)n, magic) >> sh);
 }
 
-// 16-byte non-temporal buffer store with a SCALAR offset, followed by one wait state.  gfx950 hazard (tools/dev/b128_war_check.hip):
-// a vector instruction that overwrites the data registers of a 128-bit buffer store in the very next issue slot can corrupt the last
-// dword of lanes 12-15 of each row of 16 when the memory pipeline is busy; hipcc inserts the wait state itself only when the store has
-// no scalar offset register.  Store and s_nop are one asm statement, so nothing can be scheduled between them.
+// 16-byte non-temporal buffer store with a SCALAR offset, followed by two wait states.  gfx950 hazard (tools/dev/b128_war_check.hip):
+// a vector instruction that overwrites the data registers of a 128-bit store too soon after it corrupts the last dword of lanes 12-15
+// of each row of 16 -- always for a global_store_dwordx4 overwritten in the next slot (hipcc guards those with `s_nop 1`), now and then
+// under load for a buffer store with a scalar-offset register, which hipcc does not guard.  Measured safe distance: 2 wait states for
+// the global form, 1 for the buffer form; 2 are used here.  Store and s_nop are one asm statement: nothing can be scheduled between.
 __device__ __forceinline__ void buffer_store_b128_nt(u32x4 data, __amdgpu_buffer_rsrc_t rs, unsigned voffset, int soffset) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 0" : : "v"(data), "v"(voffset), "s"(rs), "s"(soffset) : "memory");
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" : : "v"(data), "v"(voffset), "s"(rs), "s"(soffset) : "memory");
 }
 
 // magic = ceil(2^(31+L) / d) with 2^(L-1) < d <= 2^L: exact for every n < 2^31 (error term n * (magic*d - 2^(31+L)) < 2^(31+L))

@@ -46,6 +46,26 @@ __global__ void buf_case(float *out, int soff) {
       : "v10", "v11", "v12", "v13", "v20", "v21", "v22", "v23", "memory");
 }
 
+// global_store_dwordx4 (saddr form): the store the compiler emits for ordinary pointer writes
+template <int NQ, int GAP>
+__global__ void global_case(float *out) {
+  float *base = out + (size_t)blockIdx.x * 1024;
+  const unsigned addr = threadIdx.x * 16;
+  const float val = 1.0f + threadIdx.x;
+  asm volatile(
+      "v_mov_b32 v10, %1\n v_mov_b32 v11, %1\n v_mov_b32 v12, %1\n v_mov_b32 v13, %1\n"
+      "v_mov_b32 v20, 0\n v_mov_b32 v21, 0\n v_mov_b32 v22, 0\n v_mov_b32 v23, 0\n"
+      "s_nop 7\n"
+      ".rept %3\n global_store_dwordx4 %0, v[20:23], %2 offset:2048\n .endr\n"
+      "global_store_dwordx4 %0, v[10:13], %2\n"
+      ".rept %4\n s_nop 0\n .endr\n"
+      "v_mov_b32 v13, 0\n v_mov_b32 v12, 0\n v_mov_b32 v11, 0\n v_mov_b32 v10, 0\n"
+      "s_waitcnt vmcnt(0)\n"
+      :
+      : "v"(addr), "v"(val), "s"(base), "n"(NQ), "n"(GAP)
+      : "v10", "v11", "v12", "v13", "v20", "v21", "v22", "v23", "memory");
+}
+
 // the overwriter is an LDS READ returning into the store's data registers (asynchronous write-back, not a vector instruction)
 template <int NQ, int GAP>
 __global__ void buf_then_ldsread(float *out, int soff) {
@@ -98,6 +118,17 @@ int main() {
   run("6 queued, 1 s_nop between", buf_case<6, 1>, 0);
   run("6 queued, 4 s_nop between", buf_case<6, 4>, 0);
   run("6 queued, 16 s_nop between", buf_case<6, 16>, 0);
+  run("global_store_dwordx4 (scalar base), data overwritten by the next instr.", global_case<0, 0>);
+  run("6 global stores queued first, then the same", global_case<6, 0>);
+  run("global_store_dwordx4, 1 s_nop between", global_case<0, 1>);
+  run("global_store_dwordx4, 2 s_nop between", global_case<0, 2>);
+  run("global_store_dwordx4, 3 s_nop between", global_case<0, 3>);
+  run("global_store_dwordx4, 4 s_nop between", global_case<0, 4>);
+  run("6 queued + global_store_dwordx4, 2 s_nop between", global_case<6, 2>);
+  run("6 queued + global_store_dwordx4, 3 s_nop between", global_case<6, 3>);
+  run("buffer_store_dwordx4 (SGPR soffset), 1 s_nop between", buf_case<0, 1>, 0);
+  run("buffer_store_dwordx4 (SGPR soffset), 2 s_nop between", buf_case<0, 2>, 0);
+  run("buffer_store_dwordx4 (SGPR soffset), 3 s_nop between", buf_case<0, 3>, 0);
   run("buffer_store_dwordx4, then ds_read_b128 INTO its data registers", buf_then_ldsread<0, 0>, 0);
   run("6 buffer stores queued first, then the same", buf_then_ldsread<6, 0>, 0);
   run("24 buffer stores queued first, then the same", buf_then_ldsread<24, 0>, 0);
