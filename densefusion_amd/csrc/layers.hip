@@ -263,8 +263,14 @@ __global__ __launch_bounds__(TPB) void upconv_gather_kernel(const float *__restr
 
 // LDS-tiled form of the kernel above: a workgroup owns an 8 x 16 tile of output pixels and 16 output channels.  The
 // low-resolution rows / columns its 3x3 taps interpolate from (<= 7 x 11 pixels) are staged in LDS once, all nine tap
-// blocks of the 16 channels (<= 44 KB), so the 36 vector reads per output vector come from LDS and global traffic drops
+// blocks of the 16 channels (44 KB), so the 36 vector reads per output vector come from LDS and global traffic drops
 // from 36 to ~5.4 vector reads per output vector.  thread = (pixel of the tile, 4 channels).
+// Written for few instructions (this kernel issued half of all the vector instructions of the step's memory-bound kernels, and
+// next to another step's GEMM those are issue time its MFMA waves lose): the staged window always has the full 7 x 11 shape
+// (rows / columns past the map edge are clamped duplicates nobody reads), so every index decomposition divides by a constant;
+// taps outside the upsampled image keep their place in the sum with zero weights (acc + 0 * v = acc: same bits as skipping them)
+// instead of branching; the four corner addresses of a tap are row offset + column offset, the tap itself an immediate.
+typedef unsigned int u32x4l __attribute__((ext_vector_type(4)));
 constexpr int UG_TY = 8, UG_TX = 16, UG_CC = 16, UG_RH = 7, UG_RW = 11;
 
 __global__ __launch_bounds__(512) void upconv_gather_tiled_kernel(const float *__restrict__ y, const float *__restrict__ bias,
@@ -276,47 +282,67 @@ __global__ __launch_bounds__(512) void upconv_gather_tiled_kernel(const float *_
   const float sw = OW > 1 ? (float)(w - 1) / (float)(OW - 1) : 0.f;
   const int b = blockIdx.z / chunks, c0 = (blockIdx.z % chunks) * UG_CC;
   const int Y0 = blockIdx.y * UG_TY, X0 = blockIdx.x * UG_TX;
-  // low-resolution window covering every tap of the tile
-  int r_lo, r_hi, c_lo, c_hi, dummy;
+  // first low-resolution row / column any tap of the tile interpolates from (the window then spans <= 7 x 11 from there)
+  int r_lo, c_lo, dummy;
   float fd0, fd1;
   src_ac(max(Y0 - 1, 0), sh, h, r_lo, dummy, fd0, fd1);
-  src_ac(min(Y0 + UG_TY, OH - 1), sh, h, dummy, r_hi, fd0, fd1);
   src_ac(max(X0 - 1, 0), sw, w, c_lo, dummy, fd0, fd1);
-  src_ac(min(X0 + UG_TX, OW - 1), sw, w, dummy, c_hi, fd0, fd1);
-  const int RH = r_hi - r_lo + 1, RW = c_hi - c_lo + 1;          // <= UG_RH, UG_RW
-  const int nvec = RH * RW * 9 * (UG_CC / 4);
-  for (int i = threadIdx.x; i < nvec; i += 512) {
-    const int c4 = i & 3;
-    int r = i >> 2;
-    const int tap = r % 9; r /= 9;
-    const int lx = r % RW, ly = r / RW;
-    reinterpret_cast<f32x4 *>(s_y)[i] =
-        *reinterpret_cast<const f32x4 *>(y + ((size_t)(b * h + r_lo + ly) * w + c_lo + lx) * ldy + tap * Cout + c0 + c4 * 4);
+  // staging: thread = (one of 14 pixel slots, tap, channel vector) -- 36 vectors per low-resolution pixel, 77 pixels in 6 rounds;
+  // 32-bit offsets off a buffer descriptor over this image's rows
+  {
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(y + (size_t)b * h * w * ldy + c0), 0,
+                                                        (unsigned)(((size_t)h * w * ldy - c0) * sizeof(float)), 0x00020000);
+    const int slot = threadIdx.x / 36, tc = threadIdx.x - slot * 36;      // tc = tap * 4 + c4
+    const unsigned tc_off = (unsigned)((tc >> 2) * Cout + (tc & 3) * 4) * 4u;
+    const unsigned pix_bytes = (unsigned)ldy * 4u, row_bytes = (unsigned)w * pix_bytes;
+    if (slot < 14) {
+#pragma unroll
+      for (int it = 0; it < (UG_RH * UG_RW + 13) / 14; ++it) {
+        const int pix = slot + 14 * it;
+        if (pix < UG_RH * UG_RW) {
+          const int ly = pix / UG_RW, lx = pix - ly * UG_RW;
+          const int gy = min(r_lo + ly, h - 1), gx = min(c_lo + lx, w - 1);
+          const unsigned off = __umul24((unsigned)gy, row_bytes) + __umul24((unsigned)gx, pix_bytes) + tc_off;      // 24-bit factors: host-checked
+          reinterpret_cast<u32x4l *>(s_y)[pix * 36 + tc] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
+        }
+      }
+    }
   }
   __syncthreads();
   const int c4 = threadIdx.x & 3, pt = threadIdx.x >> 2;
   const int py = Y0 + pt / UG_TX, px = X0 + pt % UG_TX;
   if (py >= OH || px >= OW) return;
   const Tap3 ty = taps_for(py, sh, h, OH), tx = taps_for(px, sw, w, OW);
+  // LDS vector index of (row a of tap row dy) / (column b of tap column dx); weights of taps outside the image are zero
+  int ro[3][2], co[3][2];
+  float wy[3][2], wx[3][2];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    ro[d][0] = (ty.ok[d] ? ty.i0[d] - r_lo : 0) * (UG_RW * 36);
+    ro[d][1] = (ty.ok[d] ? ty.i1[d] - r_lo : 0) * (UG_RW * 36);
+    co[d][0] = (tx.ok[d] ? tx.i0[d] - c_lo : 0) * 36 + c4;
+    co[d][1] = (tx.ok[d] ? tx.i1[d] - c_lo : 0) * 36 + c4;
+    wy[d][0] = ty.ok[d] ? ty.w0[d] : 0.f; wy[d][1] = ty.ok[d] ? ty.w1[d] : 0.f;
+    wx[d][0] = tx.ok[d] ? tx.w0[d] : 0.f; wx[d][1] = tx.ok[d] ? tx.w1[d] : 0.f;
+  }
   const float slope = prelu[0];
   f32x4 acc = *reinterpret_cast<const f32x4 *>(bias + c0 + c4 * 4);
-  const f32x4 *sv = reinterpret_cast<const f32x4 *>(s_y) + c4;
+  const f32x4 *sv = reinterpret_cast<const f32x4 *>(s_y);
 #pragma unroll
   for (int dy = 0; dy < 3; ++dy) {
-    if (!ty.ok[dy]) continue;
-    const int l0 = (ty.i0[dy] - r_lo) * RW, l1 = (ty.i1[dy] - r_lo) * RW;
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
-      if (!tx.ok[dx]) continue;
-      const int tap = dy * 3 + dx, x0 = tx.i0[dx] - c_lo, x1 = tx.i1[dx] - c_lo;
-      const f32x4 v00 = sv[((l0 + x0) * 9 + tap) * 4], v01 = sv[((l0 + x1) * 9 + tap) * 4];
-      const f32x4 v10 = sv[((l1 + x0) * 9 + tap) * 4], v11 = sv[((l1 + x1) * 9 + tap) * 4];
+      const int tap = dy * 3 + dx;
+      const f32x4 v00 = sv[ro[dy][0] + co[dx][0] + tap * 4], v01 = sv[ro[dy][0] + co[dx][1] + tap * 4];
+      const f32x4 v10 = sv[ro[dy][1] + co[dx][0] + tap * 4], v11 = sv[ro[dy][1] + co[dx][1] + tap * 4];
       // the four corner weights once per tap, then 4 fused multiply-adds per channel (packed pairs on gfx950)
-      const float w00 = ty.w0[dy] * tx.w0[dx], w01 = ty.w0[dy] * tx.w1[dx], w10 = ty.w1[dy] * tx.w0[dx], w11 = ty.w1[dy] * tx.w1[dx];
-      acc = __builtin_elementwise_fma(v00, f32x4{w00, w00, w00, w00}, acc);
-      acc = __builtin_elementwise_fma(v01, f32x4{w01, w01, w01, w01}, acc);
-      acc = __builtin_elementwise_fma(v10, f32x4{w10, w10, w10, w10}, acc);
-      acc = __builtin_elementwise_fma(v11, f32x4{w11, w11, w11, w11}, acc);
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const f32x2 wxp = {wx[dx][0], wx[dx][1]};
+      const f32x2 w0 = f32x2{wy[dy][0], wy[dy][0]} * wxp, w1 = f32x2{wy[dy][1], wy[dy][1]} * wxp;      // (w00, w01), (w10, w11)
+      acc = __builtin_elementwise_fma(v00, f32x4{w0.x, w0.x, w0.x, w0.x}, acc);
+      acc = __builtin_elementwise_fma(v01, f32x4{w0.y, w0.y, w0.y, w0.y}, acc);
+      acc = __builtin_elementwise_fma(v10, f32x4{w1.x, w1.x, w1.x, w1.x}, acc);
+      acc = __builtin_elementwise_fma(v11, f32x4{w1.y, w1.y, w1.y, w1.y}, acc);
     }
   }
 #pragma unroll
@@ -609,7 +635,8 @@ void launch_upconv_gather(const float *y, const float *bias, const float *prelu,
                           hipStream_t st) {
   static const bool plain = getenv("DF_UPCONV_PLAIN") != nullptr;      // dev switch: the un-tiled kernel
   const long gz = (long)B * (Cout / UG_CC);
-  if (!plain && Cout % UG_CC == 0 && gz <= 65535) {
+  if (!plain && Cout % UG_CC == 0 && gz <= 65535 && (long)w * 9 * Cout * 4 < (1L << 24) && h < (1 << 24) &&
+      (long)h * w * 9 * Cout * 4 < (1L << 32)) {
     dim3 grid((2 * w + UG_TX - 1) / UG_TX, (2 * h + UG_TY - 1) / UG_TY, (unsigned)gz);
     hipLaunchKernelGGL(upconv_gather_tiled_kernel, grid, dim3(512), 0, st, y, bias, prelu, out, B, h, w, Cout);
     return;
