@@ -305,7 +305,7 @@ def bench_entry_point(est, ref, device, windows=9, frames=56):
             k += 1
     label = torch.from_numpy(label_np).pin_memory()
     from collections import deque
-    depth_ = 3
+    depth_ = int(os.environ.get("DF_BENCH_ENTRY_DEPTH", "4"))
     we = WindowEstimator(est, ref, N_PTS, ITERS, frames, (IH, IW), depth=depth_)
     for _ in range(depth_ + 1):                           # warm-up: every slot's workspace sized
         WindowEstimator.collect(we.submit(rgb, depth, label, dets))

@@ -28,7 +28,7 @@ from .network import PoseEstimator
 
 class WindowEstimator:
     def __init__(self, estimator, refiner, num_points, iteration, max_frames, frame_hw=(pp.IMG_WIDTH, pp.IMG_LENGTH), cam=pp.YCB_CAM,
-                 depth=3):
+                 depth=4):
         self.depth = max(1, int(depth))
         self.num_points, self.iteration, self.cam = int(num_points), int(iteration), cam
         self.dev = next(estimator.parameters()).device

@@ -60,7 +60,7 @@ def build_parser():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--window", type=int, default=32, help="keyframes per device call (1 = frame by frame)")
     ap.add_argument("--workers", type=int, default=8, help="PNG / .mat reader threads")
-    ap.add_argument("--depth", type=int, default=3, help="windows in flight on the device (own stream and workspace each)")
+    ap.add_argument("--depth", type=int, default=4, help="windows in flight on the device (own stream and workspace each)")
     return ap
 
 
