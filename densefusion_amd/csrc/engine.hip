@@ -1017,6 +1017,15 @@ extern "C" int df_estimate_poses(df_net *pn, df_net *rf, int B, int H, int W, co
 
 static int conv_desc_to_params(const df_conv_desc *d, ConvParams &p, const char *what);
 
+// split-K scratch of the stand-alone convolution entry points (training path; the engine's forward never uses it)
+static float *g_splitk_ws = nullptr;
+static size_t g_splitk_bytes = 0;
+extern "C" int df_conv_splitk_scratch(void *ptr, size_t bytes) {
+  g_splitk_ws = static_cast<float *>(ptr);
+  g_splitk_bytes = ptr ? bytes : 0;
+  return DF_OK;
+}
+
 extern "C" int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream) {
   if (!d) return set_error(DF_ERR_ARG, "conv2d_nhwc: null descriptor");
   if (d->KH != d->KW) return set_error(DF_ERR_ARG, "conv2d_nhwc: square kernels only");
@@ -1029,6 +1038,7 @@ extern "C" int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream) {
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.act = d->act;
   if (p.OH != conv_out(p.H, p.KH, p.stride, p.pad, p.dil) || p.OW != conv_out(p.W, p.KW, p.stride, p.pad, p.dil))
     return set_error(DF_ERR_ARG, "conv2d_nhwc: OH/OW do not match the convolution geometry");
+  p.splitk_ws = g_splitk_ws; p.splitk_ws_bytes = g_splitk_bytes;
   return launch_conv(p, to_stream(stream));
 }
 
@@ -1120,6 +1130,7 @@ extern "C" int df_conv2d_dgrad_nhwc(const df_conv_desc *d, const float *dy, floa
   q.KH = f.KH; q.KW = f.KW; q.stride = 1; q.up = f.stride; q.dil = f.dil; q.pad = f.dil * (f.KH - 1) - f.pad;
   if (q.pad < 0) return set_error(DF_ERR_ARG, "conv2d_dgrad: padding larger than the kernel reach is not supported");
   if (accumulate) { q.res = dx; q.res_ld = f.in_ld; q.res_coff = f.in_coff; }
+  q.splitk_ws = g_splitk_ws; q.splitk_ws_bytes = g_splitk_bytes;
   return launch_conv(q, st);
 }
 

@@ -34,6 +34,12 @@ struct ConvParams {
   int ngroup = 0;   // column tiles per L2-resident weight group (0 = one group); set by launch_conv
   long z_in_coff = 0, z_wgt = 0, z_bias = 0, z_out_coff = 0;
   // magic pairs for the kernels' divisions by OH*OW and OW (set by the launchers)
+  // split-K (training path only: opt-in through a registered scratch, df_conv_splitk_scratch): launches that would fill less than
+  // half the chip cut their reduction into `splitk` ranges (blockIdx.z), partial sums go to the scratch and a fixed-order reduce
+  // kernel adds them and applies bias / residual / activation (deterministic).  splitk is set by launch_conv.
+  float *splitk_ws = nullptr;
+  size_t splitk_ws_bytes = 0;
+  int splitk = 1;
   // tile decode of the v4 kernel without integer divisions (set by launch_conv): row-tile count, tiles per full weight group, and
   // division magics (make_fdiv) for the group size, the widths of a full / the last group and rows_per_group
   int tiles_m = 0, tile_gn = 0, tile_full = 0;

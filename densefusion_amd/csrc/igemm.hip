@@ -777,8 +777,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   // columns 8q + 4lh .. +3 in acc[4q .. 4q+3] -- four consecutive output channels of one pixel: the epilogue stages a band with 8
   // ds_write_b128 per lane instead of 32 ds_write2_b32.  Same products, same order per output element.)
 
+  // split-K launches (p.splitk > 1): blockIdx.z selects this workgroup's range of k tiles
+  const int kt_begin = p.splitk > 1 ? (int)((long)z * nkt / p.splitk) : 0;
+  const int kt_end = p.splitk > 1 ? (int)((long)(z + 1) * nkt / p.splitk) : nkt;
   DF_TRACE(0);
-  issue_loads(0);
+  issue_loads(kt_begin);
   DF_TRACE(1);
   using std::integral_constant;
   auto k_tile = [&](int kt, auto first) {
@@ -786,7 +789,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     write_lds();                         // tile kt: registers -> LDS (waits for its loads)
     // tile kt+1 flies while tile kt multiplies.  Past the end the general loader's offsets are out of range (zeros, no traffic);
     // the scalar-offset loaders would fetch the next 128 bytes of every row (+6 % reads at K = 512, +17 % at K = 192): skipped
-    if (LOADER == 0 || kt + 1 < nkt) issue_loads(kt + 1);
+    if (LOADER == 0 || kt + 1 < kt_end) issue_loads(kt + 1);
     __syncthreads();
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) {
@@ -797,8 +800,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     }
     __syncthreads();                     // every wave has read tile kt before tile kt+1 overwrites it
   };
-  k_tile(0, integral_constant<bool, true>{});          // (K >= 1: there is always a first tile)
-  for (int kt = 1; kt < nkt; ++kt) k_tile(kt, integral_constant<bool, false>{});
+  k_tile(kt_begin, integral_constant<bool, true>{});          // (there is always a first tile)
+  for (int kt = kt_begin + 1; kt < kt_end; ++kt) k_tile(kt, integral_constant<bool, false>{});
   DF_TRACE(2);
 
   // ---- epilogue: accumulators -> LDS (per-wave region) -> 16-byte row segments, one 32-row band of the wave tile at a time (the
@@ -908,6 +911,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   }
   DF_TRACE(3);
   DF_TRACE_WAVE_END(wave);
+}
+
+// split-K reduce: out = act(sum_s partial[s] + bias + res), partials added in the order s = 0, 1, ... (deterministic).  thread = 4 channels
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int S, long M, int Cout, float *__restrict__ out,
+                                                            int out_ld, int out_coff, const float *__restrict__ bias,
+                                                            const float *__restrict__ res, int res_ld, int res_coff, int act,
+                                                            const float *__restrict__ prelu) {
+  const int c4n = Cout >> 2;
+  const long total = M * c4n, plane = M * Cout;
+  const float slope = act == ACT_PRELU ? prelu[0] : 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / c4n;
+    const int c = (int)(i - m * c4n) << 2;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(ws + m * Cout + c);
+    for (int s2 = 1; s2 < S; ++s2) v += *reinterpret_cast<const f32x4 *>(ws + s2 * plane + m * Cout + c);
+    if (bias) v += *reinterpret_cast<const f32x4 *>(bias + c);
+    if (res) v += *reinterpret_cast<const f32x4 *>(res + m * res_ld + res_coff + c);
+    if (act == ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    } else if (act == ACT_PRELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+    }
+    *reinterpret_cast<f32x4 *>(out + m * out_ld + out_coff + c) = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1292,22 +1321,39 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
     }
   }
   constexpr size_t ROW = 36 * sizeof(float);      // one padded k-tile row (BKT = 32)
+  // workgroups per CU of the v4 kernel: 4 / 5 / 6 (the register budget amdgpu_waves_per_eu leaves each: 128 / 102 / 85 VGPRs + AGPRs)
+  static const bool no_pure = getenv("DF_IGEMM_NOPURE") != nullptr;      // dev switch: the general loader for every launch; read once
+  const bool v4 = takes_v4(p);
+  const int taps = p.KH * p.KW;
+  const size_t shifted = ((size_t)p.B * p.H * p.W + (size_t)p.pad * p.W + p.pad) * p.in_ld * sizeof(float);
+  // loader 1: plain GEMM; loader 2: several taps, every 32-wide k tile inside one tap, tap mask in 32 bits, offsets below 2^31
+  const int loader = no_pure ? 0
+                     : taps == 1 && p.stride == 1 && p.pad == 0 && p.Cin % 32 == 0 ? 1
+                     : taps > 1 && taps <= 32 && p.Cin >= 32 && shifted < (1ull << 31) ? 2 : 0;     // (Cin is a power of two here)
+  // split-K (opt-in scratch; training): a grid under one workgroup per CU with a long reduction
+  int S = 1;
+  if (v4 && p.splitk_ws && !p.colsum && p.zcount == 1 && loader != 0 && tiles < 256 && p.bias_group_ld == 0 && p.rows_per_group == 0) {
+    const int nkt = (p.KH * p.KW * p.Cin) / 32;
+    S = (int)std::min<long>(8, (512 + tiles - 1) / tiles);
+    S = std::min(S, nkt / 4);
+    while (S > 1 && (size_t)S * M * p.Cout * sizeof(float) > p.splitk_ws_bytes) --S;
+    if ((long)S * M * p.Cout >= (1L << 31)) S = 1;
+    if (S < 1) S = 1;
+  }
+  if (S > 1) {
+    pl.splitk = S;
+    pl.out = p.splitk_ws; pl.out_ld = p.Cout; pl.out_coff = 0; pl.z_out_coff = M * p.Cout;
+    pl.bias = nullptr; pl.res = nullptr; pl.act = ACT_NONE;
+    grid.z = S;
+  }
   // grids under two workgroups per CU: the software-pipelined kernel (training, 1 / 8 frames per pass: 142 -> 154 / 670 -> 696 frames/s)
   static const long lowocc = getenv("DF_IGEMM_LOWOCC") ? atol(getenv("DF_IGEMM_LOWOCC")) : 512;    // dev switch; read once
-  if (takes_v4(p) && tiles * p.zcount < lowocc && c.bn == c.bm) {
+  if (v4 && S == 1 && tiles * p.zcount < lowocc && c.bn == c.bm) {
     if (c.bm == 128)
       hipLaunchKernelGGL((igemm_f32_v2_kernel<128, 128, 2, 2, 32>), grid, dim3(256), (size_t)2 * 256 * 36 * sizeof(float), st, pl);
     else
       hipLaunchKernelGGL((igemm_f32_v2_kernel<64, 64, 2, 2, 32>), grid, dim3(256), (size_t)2 * 128 * 36 * sizeof(float), st, pl);
-  } else if (takes_v4(p)) {
-    // workgroups per CU: 4 / 5 / 6 (the register budget amdgpu_waves_per_eu leaves each: 128 / 102 / 85 VGPRs + AGPRs)
-    static const bool no_pure = getenv("DF_IGEMM_NOPURE") != nullptr;      // dev switch: the general loader for every launch; read once
-    const int taps = p.KH * p.KW;
-    const size_t shifted = ((size_t)p.B * p.H * p.W + (size_t)p.pad * p.W + p.pad) * p.in_ld * sizeof(float);
-    // loader 1: plain GEMM; loader 2: several taps, every 32-wide k tile inside one tap, tap mask in 32 bits, offsets below 2^31
-    const int loader = no_pure ? 0
-                       : taps == 1 && p.stride == 1 && p.pad == 0 && p.Cin % 32 == 0 ? 1
-                       : taps > 1 && taps <= 32 && p.Cin >= 32 && shifted < (1ull << 31) ? 2 : 0;     // (Cin is a power of two here)
+  } else if (v4) {
     auto launch = [&](auto bm, auto bn, auto occ, size_t rows) {
       constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value, OCC_ = decltype(occ)::value;
       if (loader == 1) hipLaunchKernelGGL((igemm_f32_v4_kernel<BM_, BN_, 2, 2, 32, OCC_, 1, false>), grid, dim3(256), rows * ROW, st, pl);
@@ -1322,6 +1368,11 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
     } else if (c.bm == 128 && c.bn == 128) launch(integral_constant<int, 128>{}, integral_constant<int, 128>{}, integral_constant<int, 4>{}, 256);
     else if (c.bm == 128) launch(integral_constant<int, 128>{}, integral_constant<int, 64>{}, integral_constant<int, 5>{}, 192);
     else launch(integral_constant<int, 64>{}, integral_constant<int, 64>{}, integral_constant<int, 6>{}, 128);      // (a BK = 64 form of the small tile was measured: 0.85-1.0x, dropped)
+    if (S > 1) {
+      const long vecs = M * (p.Cout / 4);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>((vecs + 255) / 256, 65535L * 8)), dim3(256), 0, st, p.splitk_ws, S, M, p.Cout,
+                         p.out, p.out_ld, p.out_coff, p.bias, p.res, p.res_ld, p.res_coff, p.act, p.prelu);
+    }
   } else if (c.bm == 128) {
     hipLaunchKernelGGL((igemm_f32_kernel<128, 128, 2, 2>), grid, dim3(256), (size_t)2 * 256 * LDK * sizeof(float), st, p);
   } else {

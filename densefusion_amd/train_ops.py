@@ -3,6 +3,7 @@ the tape; every forward and backward below is a HIP launch through the C ABI."""
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -57,6 +58,32 @@ def _conv_flops(x, w, y):
     return 2.0 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
 
 
+_SPLITK = {}          # device index -> persistent scratch tensor
+
+
+class _splitk:
+    """Registers the split-K scratch (df_conv_splitk_scratch) for the launches inside the block: the convolutions of a training pass on
+    small maps (layer3 / layer4: a few hundred pixels, reductions of 2304 / 4608) otherwise launch far fewer tiles than the chip has CUs.
+    Deterministic (fixed-order reduce); off with DF_TRAIN_NO_SPLITK=1."""
+
+    def __init__(self, device):
+        self.dev = device
+
+    def __enter__(self):
+        if os.environ.get("DF_TRAIN_NO_SPLITK"):
+            return self
+        key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        buf = _SPLITK.get(key)
+        if buf is None:
+            buf = _SPLITK[key] = torch.empty(64 << 20, dtype=torch.uint8, device=self.dev)
+        _ck(_lib.lib().df_conv_splitk_scratch(buf.data_ptr(), buf.numel()), "conv_splitk_scratch")
+        return self
+
+    def __exit__(self, *a):
+        _lib.lib().df_conv_splitk_scratch(None, 0)
+        return False
+
+
 class ConvAct(torch.autograd.Function):
     """y = act(conv(x, w) + bias + res): ONE fused MFMA launch forward; backward = activation gradient kernel, then the
     data-gradient (same MFMA kernel, flipped weights) and weight/bias-gradient MFMA kernels."""
@@ -64,7 +91,7 @@ class ConvAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, res, slope, stride, pad, dil, act):
         x, w = x.contiguous(), w.contiguous()
-        with _Timed("fwd", 0.0) as _t:
+        with _Timed("fwd", 0.0) as _t, _splitk(x.device):
             y = conv2d_nhwc(x, w, bias, stride=stride, pad=pad, dil=dil, act=act, res=res.contiguous() if res is not None else None,
                             prelu=slope)
         if _PROFILE is not None and _PROFILE["fwd"]:
@@ -95,7 +122,7 @@ class ConvAct(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 scratch = torch.empty_like(w)
-                with _Timed("dgrad", _conv_flops(x, w, y)):
+                with _Timed("dgrad", _conv_flops(x, w, y)), _splitk(x.device):
                     _ck(L.df_conv2d_dgrad_nhwc(ctypes.byref(d), g.data_ptr(), dx.data_ptr(), scratch.data_ptr(), 0, _st()), "conv2d_dgrad")
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                 dw = torch.empty_like(w)

@@ -211,6 +211,12 @@ typedef struct df_conv_desc {
   int32_t KH, KW, stride, pad, dil, act;
 } df_conv_desc;
 int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream);
+/* Training path: register `bytes` of device scratch (NULL: unregister).  While registered, df_conv2d_nhwc and df_conv2d_dgrad_nhwc
+ * cut the reduction of launches that would fill less than half the chip (a few hundred pixels x a few thousand taps*channels: the
+ * layer3 / layer4 convolutions of a training pass) into up to 8 ranges, keep the partial sums in the scratch and add them in a fixed
+ * order with bias / residual / activation (deterministic; results differ from the unsplit launch by fp32 re-association).  Process-wide,
+ * one stream at a time; the engine entry points (df_posenet_forward, df_estimate_poses*) never split. */
+int df_conv_splitk_scratch(void *ptr, size_t bytes);
 
 /* The same operator for 3x3 / stride 1 / pad == dil (any dilation) evaluated through the Winograd F(2x2,3x3) domain:
  * 16 multiplies per 2x2 outputs instead of 36 (the path the engine takes for the 256/512-channel convs of the

@@ -271,3 +271,56 @@ def test_specialised_loaders_are_bit_identical_to_the_general_one(tmp_path):
     assert len(a) == len(b) == 5
     for i, (u, v) in enumerate(zip(a, b)):
         assert torch.equal(u, v), f"case {i}: loaders disagree, max diff {float((u - v).abs().max())}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [
+    # (B, H, W, Cin, Cout, k, pad, dil): the layer3 / layer4 shapes of an 8-frame training pass (few tiles, long reductions) and a 1x1
+    (8, 20, 20, 512, 512, 3, 4, 4), (8, 20, 20, 256, 256, 3, 2, 2), (4, 15, 20, 256, 512, 3, 4, 4), (8, 20, 20, 2048, 256, 1, 0, 1),
+    (1, 20, 20, 512, 512, 3, 4, 4),
+])
+def test_splitk_convolution(geom):
+    """Opt-in split-K (df_conv_splitk_scratch, what the training ops register): against an fp64 convolution, against the unsplit launch
+    (fp32 re-association only), bit-reproducible run to run, residual + bias + ReLU applied once by the reduce kernel -- and the data
+    gradient through the same path."""
+    import ctypes
+    from densefusion_amd import _lib, train_ops
+    from densefusion_amd.ops import conv2d_nhwc, _desc
+    B, H, W, Cin, Cout, k, pad, dil = geom
+    dev = torch.device("cuda:0")
+    torch.manual_seed(sum(geom))
+    x = torch.randn(B, H, W, Cin, device=dev)
+    w = torch.randn(Cout, k, k, Cin, device=dev) * (1.0 / (k * k * Cin)) ** 0.5
+    bias = torch.randn(Cout, device=dev)
+    res = torch.randn(B, H, W, Cout, device=dev)
+    want = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), bias.double(), 1, pad, dil)
+                      .permute(0, 2, 3, 1) + res.double())
+    plain = conv2d_nhwc(x, w, bias, stride=1, pad=pad, dil=dil, act=1, res=res)
+    with train_ops._splitk(dev):
+        a = conv2d_nhwc(x, w, bias, stride=1, pad=pad, dil=dil, act=1, res=res)
+        b = conv2d_nhwc(x, w, bias, stride=1, pad=pad, dil=dil, act=1, res=res)
+    assert torch.equal(a, b), "split-K is not reproducible run to run"
+    scale = max(1.0, float(want.abs().max()))
+    assert float((a.double() - want).abs().max()) <= 2e-5 * scale
+    assert float((a - plain).abs().max()) <= 2e-5 * scale
+    if B > 1:
+        assert not torch.equal(a, plain) or True          # (the split launch may or may not change the bits; only the bound above is required)
+    # data gradient: dx = conv_transpose(dy, w)
+    dy = torch.randn(B, H, W, Cout, device=dev)
+    d = _desc(x, w, None, 1, pad, dil)
+    L = _lib.lib()
+    outs = []
+    for use in (False, True, True):
+        dx = torch.empty_like(x)
+        scratch = torch.empty_like(w)
+        if use:
+            with train_ops._splitk(dev):
+                _lib.check(L.df_conv2d_dgrad_nhwc(ctypes.byref(d), dy.data_ptr(), dx.data_ptr(), scratch.data_ptr(), 0, _lib.current_stream()), "dgrad")
+        else:
+            _lib.check(L.df_conv2d_dgrad_nhwc(ctypes.byref(d), dy.data_ptr(), dx.data_ptr(), scratch.data_ptr(), 0, _lib.current_stream()), "dgrad")
+        outs.append(dx)
+    want_dx = torch.nn.grad.conv2d_input((B, Cin, H, W), w.permute(0, 3, 1, 2).double(), dy.permute(0, 3, 1, 2).double(), 1, pad, dil).permute(0, 2, 3, 1)
+    assert torch.equal(outs[1], outs[2])
+    s2 = max(1.0, float(want_dx.abs().max()))
+    assert float((outs[1].double() - want_dx).abs().max()) <= 3e-5 * s2
+    assert float((outs[0].double() - want_dx).abs().max()) <= 3e-5 * s2
