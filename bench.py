@@ -348,7 +348,9 @@ def bench_train(device):
     for j in range(acc):
         o = synth.make_object(500 + j, H, W, N, K, M)
         o["obj"][0] = [12, 3, 15, 7][j % 4]                         # every other frame is a symmetric object (KNN loss branch)
-        frames.append({k: torch.from_numpy(v).to(device) for k, v in o.items()})
+        fd = {k: torch.from_numpy(v).to(device) for k, v in o.items()}
+        train_utils.with_host_index(fd["obj"], o["obj"])           # what a data loader does: the losses branch on the index without a read-back
+        frames.append(fd)
 
     def step(fr):
         img = torch.stack([f["img"] for f in fr]); cloud = torch.stack([f["cloud"] for f in fr])
@@ -356,7 +358,7 @@ def bench_train(device):
         r, t, c, emb = net(img, cloud, choose, obj)
         loss = 0
         for b, f in enumerate(fr):
-            loss = loss + crit(r[b:b + 1], t[b:b + 1], c[b:b + 1], f["target"][None], f["model_points"][None], f["obj"][None], f["cloud"][None],
+            loss = loss + crit(r[b:b + 1], t[b:b + 1], c[b:b + 1], f["target"][None], f["model_points"][None], f["obj"], f["cloud"][None],
                                0.015, False)[0]
         loss.backward()
 

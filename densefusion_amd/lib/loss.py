@@ -17,6 +17,7 @@ from __future__ import annotations
 import torch
 
 from .. import _lib
+from ..train_utils import host_index
 
 
 def _f32(t):
@@ -71,7 +72,7 @@ class Loss:
             raise RuntimeError("Loss.forward: expected bs = 1, target/model_points [1,M,3], points [1,N,3]")
         if not pred_r.is_cuda:
             raise RuntimeError("densefusion_amd needs device tensors (no CPU path)")
-        sym = (not refine) and int(idx.reshape(-1)[0].item()) in self.sym_list
+        sym = (not refine) and host_index(idx) in self.sym_list
         return _LossFn.apply(pred_r, pred_t, pred_c, target, model_points, points, w, sym, M)
 
     __call__ = forward

@@ -10,6 +10,7 @@ import torch
 
 from .. import _lib
 from .loss import _f32
+from ..train_utils import host_index
 
 
 class _LossRefineFn(torch.autograd.Function):
@@ -55,7 +56,7 @@ class Loss_refine:
             raise RuntimeError("Loss_refine.forward: expected pred_r [1,4], pred_t [1,3], target/model_points [1,M,3]")
         if not pred_r.is_cuda:
             raise RuntimeError("densefusion_amd needs device tensors (no CPU path)")
-        sym = int(idx.reshape(-1)[0].item()) in self.sym_list
+        sym = host_index(idx) in self.sym_list
         return _LossRefineFn.apply(pred_r, pred_t, target, model_points, points, sym, M)
 
     __call__ = forward

@@ -120,10 +120,11 @@ def posenet_forward(net, img, x, choose, obj, dropout=True):
         y = _pc(P, f"conv2_{hname}", y)
         y = _pc(P, f"conv3_{hname}", y)
         outs[hname] = _pc(P, f"conv4_{hname}", y, relu=False).reshape(B, N, -1)
-    objs = [int(o) for o in obj.reshape(-1).tolist()]
-    out_rx = torch.stack([outs["r"][b, :, o * 4:o * 4 + 4] for b, o in enumerate(objs)])
-    out_tx = torch.stack([outs["t"][b, :, o * 3:o * 3 + 3] for b, o in enumerate(objs)])
-    conf = torch.stack([outs["c"][b, :, o:o + 1] for b, o in enumerate(objs)])
+    # the object's slice of every head, picked on the device (indexing with the index TENSOR: no read-back, no synchronisation)
+    bsel, osel = torch.arange(B, device=obj.device), obj.reshape(-1).long()
+    out_rx = outs["r"].reshape(B, N, -1, 4)[bsel, :, osel]
+    out_tx = outs["t"].reshape(B, N, -1, 3)[bsel, :, osel]
+    conf = outs["c"].reshape(B, N, -1, 1)[bsel, :, osel]
     out_cx = T.Sigmoid.apply(conf.contiguous())
     emb = emb_pm.reshape(B, N, 32).transpose(1, 2).contiguous()
     return out_rx, out_tx, out_cx, emb.detach()
@@ -145,7 +146,7 @@ def refiner_forward(net, x, emb, obj):
         y = _pc(P, f"conv1_{hname}", ap)
         y = _pc(P, f"conv2_{hname}", y)
         outs[hname] = _pc(P, f"conv3_{hname}", y, relu=False).reshape(B, -1)
-    objs = [int(o) for o in obj.reshape(-1).tolist()]
-    out_rx = torch.stack([outs["r"][b, o * 4:o * 4 + 4] for b, o in enumerate(objs)])
-    out_tx = torch.stack([outs["t"][b, o * 3:o * 3 + 3] for b, o in enumerate(objs)])
+    bsel, osel = torch.arange(B, device=obj.device), obj.reshape(-1).long()
+    out_rx = outs["r"].reshape(B, -1, 4)[bsel, osel]
+    out_tx = outs["t"].reshape(B, -1, 3)[bsel, osel]
     return out_rx, out_tx

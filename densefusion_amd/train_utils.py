@@ -66,3 +66,20 @@ class FlatAdam:
         # the update bypasses torch's version counters: tell the inference engine its parameter copies are stale
         if hasattr(f.module, "_uploaded"):
             f.module._uploaded = {}
+
+
+def with_host_index(t_dev, values):
+    """Attach the host copy of an object-index tensor to its device copy (``t._host``: list of ints).  The losses need the index on
+    the host to pick their branch (symmetric object or not); reading it back from the device (`.item()`) is a device synchronisation
+    per frame, which at the reference's one frame per pass leaves the GPU waiting for the Python side.  Callers that already hold the
+    index on the host (every data loader does) attach it; without the hint the losses fall back to `.item()`."""
+    t_dev._host = [int(v) for v in (values.reshape(-1).tolist() if hasattr(values, "reshape") else values)]
+    return t_dev
+
+
+def host_index(idx):
+    """First object index of `idx` without a device synchronisation when the hint is there (or `idx` lives on the host)."""
+    h = getattr(idx, "_host", None)
+    if h is not None:
+        return int(h[0])
+    return int(idx.reshape(-1)[0].item())

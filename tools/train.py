@@ -192,7 +192,8 @@ def main(argv=None):
         if points.dim() == 1:                       # the LineMOD loader's "lost detection" sentinel: six LongTensor([0])
             return None
         f = lambda t: t.to(dev)[None]                # add the bs = 1 axis the DataLoader of the reference adds
-        return f(points), choose.to(dev).reshape(1, 1, -1), f(img), f(target), f(model_points), idx.to(dev).reshape(1, 1)
+        return (f(points), choose.to(dev).reshape(1, 1, -1), f(img), f(target), f(model_points),
+                train_utils.with_host_index(idx.to(dev).reshape(1, 1), idx))      # host copy kept: the losses branch on it without a read-back
 
     def run_pass(frames):
         """Forward + loss + backward of `frames` (same crop size) in one pass; returns their distances."""

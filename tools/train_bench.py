@@ -26,7 +26,9 @@ def main():
         for j in range(P):
             o = synth.make_object(500 + gi * P + j, H, W, N, K, M)
             o["obj"][0] = [12, 3, 15, 7][(gi + j) % 4]          # half of the frames symmetric (KNN loss branch)
-            fr.append({k: torch.from_numpy(v).to(dev) for k, v in o.items()})
+            fd = {k: torch.from_numpy(v).to(dev) for k, v in o.items()}
+            train_utils.with_host_index(fd["obj"], o["obj"])
+            fr.append(fd)
         groups.append(fr)
     def step(fr):
         img = torch.stack([f["img"] for f in fr]); cloud = torch.stack([f["cloud"] for f in fr])
@@ -34,7 +36,7 @@ def main():
         r, t, c, emb = net(img, cloud, choose, obj)
         loss = 0
         for b, f in enumerate(fr):
-            loss = loss + crit(r[b:b + 1], t[b:b + 1], c[b:b + 1], f["target"][None], f["model_points"][None], f["obj"][None], f["cloud"][None],
+            loss = loss + crit(r[b:b + 1], t[b:b + 1], c[b:b + 1], f["target"][None], f["model_points"][None], f["obj"], f["cloud"][None],
                                0.015, False)[0]
         loss.backward()
         return loss
