@@ -353,6 +353,10 @@ def bench_train(device):
         frames.append(fd)
 
     def step(fr):
+        with train_ops.splitk_scope(device):             # one registration of the split-K scratch per pass (tools/train.py does the same)
+            return _step(fr)
+
+    def _step(fr):
         img = torch.stack([f["img"] for f in fr]); cloud = torch.stack([f["cloud"] for f in fr])
         choose = torch.stack([f["choose"] for f in fr]); obj = torch.stack([f["obj"] for f in fr])
         r, t, c, emb = net(img, cloud, choose, obj)

@@ -64,13 +64,16 @@ _SPLITK = {}          # device index -> persistent scratch tensor
 class _splitk:
     """Registers the split-K scratch (df_conv_splitk_scratch) for the launches inside the block: the convolutions of a training pass on
     small maps (layer3 / layer4: a few hundred pixels, reductions of 2304 / 4608) otherwise launch far fewer tiles than the chip has CUs.
-    Deterministic (fixed-order reduce); off with DF_TRAIN_NO_SPLITK=1."""
+    Deterministic (fixed-order reduce); off with DF_TRAIN_NO_SPLITK=1.  Re-entrant: only the outermost block talks to the library, so a
+    trainer that wraps a whole forward + backward pass in `splitk_scope` pays two calls per pass instead of two per convolution."""
+    _depth = 0
 
     def __init__(self, device):
         self.dev = device
 
     def __enter__(self):
-        if os.environ.get("DF_TRAIN_NO_SPLITK"):
+        _splitk._depth += 1
+        if _splitk._depth > 1 or os.environ.get("DF_TRAIN_NO_SPLITK"):
             return self
         key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         buf = _SPLITK.get(key)
@@ -80,8 +83,13 @@ class _splitk:
         return self
 
     def __exit__(self, *a):
-        _lib.lib().df_conv_splitk_scratch(None, 0)
+        _splitk._depth -= 1
+        if _splitk._depth == 0:
+            _lib.lib().df_conv_splitk_scratch(None, 0)
         return False
+
+
+splitk_scope = _splitk
 
 
 class ConvAct(torch.autograd.Function):

@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from densefusion_amd import synth, train_utils  # noqa: E402
+from densefusion_amd import synth, train_ops, train_utils  # noqa: E402
 from densefusion_amd.lib.loss import Loss  # noqa: E402
 from densefusion_amd.lib.loss_refiner import Loss_refine  # noqa: E402
 from densefusion_amd.lib.network import PoseNet, PoseRefineNet  # noqa: E402
@@ -197,6 +197,10 @@ def main(argv=None):
 
     def run_pass(frames):
         """Forward + loss + backward of `frames` (same crop size) in one pass; returns their distances."""
+        with train_ops.splitk_scope(dev):                # the small-map convolutions split their reductions (one registration per pass)
+            return _run_pass(frames)
+
+    def _run_pass(frames):
         points, choose, img = (torch.cat([f[k] for f in frames]) for k in (0, 1, 2))
         idx = torch.cat([f[5] for f in frames])
         if opt.refine_start:

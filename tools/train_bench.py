@@ -5,7 +5,7 @@ differentiable pass (same gradients, larger GEMMs)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from densefusion_amd import synth, train_utils
+from densefusion_amd import synth, train_ops, train_utils
 from densefusion_amd.lib.loss import Loss
 from densefusion_amd.lib.network import PoseNet
 
@@ -31,6 +31,10 @@ def main():
             fr.append(fd)
         groups.append(fr)
     def step(fr):
+        with train_ops.splitk_scope(dev):
+            return _step(fr)
+
+    def _step(fr):
         img = torch.stack([f["img"] for f in fr]); cloud = torch.stack([f["cloud"] for f in fr])
         choose = torch.stack([f["choose"] for f in fr]); obj = torch.stack([f["obj"] for f in fr])
         r, t, c, emb = net(img, cloud, choose, obj)
