@@ -29,11 +29,54 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU, the
+    environment torch.distributed.run would give them), relay rank 0's JSON line and exit with the worst child status.  Runs
+    before torch or the HIP library is imported: the parent never touches the GPU and replaces no process (no exec)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    line = None
+    for ln in (out or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if any(rcs):
+        print(f"[bench] rank exit codes {rcs}", file=sys.stderr)
+        sys.exit(next(rc for rc in rcs if rc) if all(rc >= 0 for rc in rcs) else 1)
+    if line is None or json.loads(line).get("n_gpus") != n:
+        print(f"[bench] rank 0 did not report n_gpus == {n}: {line}", file=sys.stderr)
+        sys.exit(1)
+    print(line, flush=True)
+    sys.exit(0)
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _pre = argparse.ArgumentParser(add_help=False)
+    _pre.add_argument("--gpus", type=int, default=1)
+    _n = _pre.parse_known_args()[0].gpus
+    if _n > 1:
+        spawn_ranks(_n, sys.argv[1:])
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from densefusion_amd import _lib, sharding, synth  # noqa: E402
 from densefusion_amd.lib.knn import KNearestNeighbor  # noqa: E402
@@ -502,6 +545,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: start it as `python bench.py --gpus N` (it starts its own "
+                 "ranks) or under torch.distributed.run with --nproc-per-node N")
     if "DF_BENCH_DEVICE" in os.environ:            # rehearsal only: several ranks sharing one card
         local = int(os.environ["DF_BENCH_DEVICE"])
     torch.cuda.set_device(local)
@@ -596,7 +642,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ycb_video_synthetic_stream (BASELINE configs[2] shape at the metric's 2 refine iters: "
-                                   "K=21 objects, N=1000 points, crops cycled over 80x80..240x320, 5 objects/frame)",
+                                   "K=21 objects, N=1000 points, crops cycled over 80x80..240x320, 5 objects/frame; every step "
+                                   "re-evaluates the same objects_per_step_per_gpu resident objects)",
                        "num_obj": K_OBJ, "num_points": N_PTS, "refine_iters": ITERS, "crops": CROPS,
                        "objects_per_step_per_gpu": poses_per_step, "frames_per_step_per_gpu": poses_per_step / 5,
                        "hipgraph": graph is not None, "groups": len(groups), "group_streams": streams is not None, "steps_in_flight": len(insts), "sharding": f"objects round-robin over {world} rank(s), no data-path collective",
@@ -620,7 +667,8 @@ def main():
                            "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
                            "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
                            "gemm_ms_per_step": round(ms / max(1, min(args.steps, 5)), 3)}
-        if not args.no_knn:
+        assert out["n_gpus"] == args.gpus
+        if not args.no_knn and world == 1:          # the side measurements are single-GPU figures: not repeated per scaling point
             out["knn"] = bench_knn()
             out["knn"]["symmetric_loss_forward"] = bench_loss()
             out["latency_single_object"] = bench_latency(est, ref, device)

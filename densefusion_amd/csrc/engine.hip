@@ -879,7 +879,8 @@ static int posenet_args_ok(const Net *n, int B, int H, int W) {
 
 // bucket list of a multi-bucket call (host arrays of nb entries); img may be null (workspace sizing)
 static int make_groups(const Net *n, int nb, const int *B, const int *H, const int *W, const float *const *img, std::vector<Grp> &gs) {
-  if (nb <= 0 || nb > 64 || !B || !H || !W) return set_error(DF_ERR_ARG, "need 1..64 buckets with B / H / W arrays (got nb = %d)", nb);
+  // 4096: far above the 12 x 16 = 192 crop sizes the datasets' 40-pixel snapping can produce (datasets/ycb/dataset.py:247-289)
+  if (nb <= 0 || nb > 4096 || !B || !H || !W) return set_error(DF_ERR_ARG, "need 1..4096 buckets with B / H / W arrays (got nb = %d)", nb);
   long tot = 0;
   gs.clear();
   for (int i = 0; i < nb; ++i) {

@@ -46,6 +46,24 @@ def allreduce_gradients(flat: FlatParams, group=None):
     return 1
 
 
+def replicas_in_sync(modules, group=None):
+    """True when every rank holds the same parameters in `modules`: per tensor a (sum, sum of squares) checksum in fp64, gathered
+    through host memory (a few KB, any backend) and compared exactly.  tools/train.py calls it once after initialisation /
+    resume: data-parallel replicas that start apart are averaged by every gradient all-reduce and never meet again."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return True
+    sums = []
+    for m in modules:
+        for p in m.parameters():
+            d = p.detach().double()
+            sums += [d.sum(), (d * d).sum()]
+    mine = torch.stack(sums).cpu() if sums else torch.zeros(0, dtype=torch.float64)
+    every = [None] * dist.get_world_size(group)
+    dist.all_gather_object(every, mine.tolist(), group=group)
+    return all(e == every[0] for e in every)
+
+
 class FlatAdam:
     def __init__(self, flat: FlatParams, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
         self.flat, self.lr, self.betas, self.eps = flat, float(lr), betas, eps

@@ -39,3 +39,27 @@ def test_bench_json_contract():
     for k in ("knn", "train", "entry_point", "latency_single_object"):
         assert k in d, k
     assert d["entry_point"]["lost"] == 0 and d["entry_point"]["entry_point_poses_per_s"] > 0
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two rank processes itself (gloo, both on the one card of a
+    test box -- a rehearsal of the N-GPU command the driver issues) and relays rank 0's line with n_gpus == 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(DF_BENCH_DEVICE="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                          "--per-bucket", "2", "--inflight", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
+    poses = d["config"]["objects_per_step_per_gpu"] * 2 * d["steps"]                  # whole-job aggregate over both ranks
+    assert abs(d["value"] - poses / (d["ms_per_step"] * d["steps"] / 1e3)) <= 0.01 * d["value"]
+    assert "roofline" in d and "cpu_baseline" not in d                                 # the CPU leg runs at N = 1 only
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr and not out.stdout.strip()

@@ -287,6 +287,25 @@ def test_multi_bucket_call_equals_per_bucket_calls():
         pe.estimate_multi([T(bs[0], "img")], cat("cloud"), cat("choose"), cat("obj"), 2)      # object counts disagree
 
 
+def test_a_window_with_more_than_64_crop_sizes():
+    """40-pixel snapping yields up to 12 x 16 crop sizes, so a long evaluation window can hold more than 64 of them (the limit of
+    df_estimate_poses_multi until round 3): 70 one-object buckets in one call == the same objects evaluated size by size."""
+    from densefusion_amd.lib.network import PoseEstimator
+    K, N = 3, 128
+    est, ref = _nets(K, N, 17)
+    pe = PoseEstimator(est, ref)
+    shapes = [(1, H, W) for H in (40, 80, 120, 160, 200) for W in range(40, 40 * 15, 40)]
+    assert len(shapes) == 70
+    bs = [synth.make_batch(900 + i, B, H, W, N, K) for i, (B, H, W) in enumerate(shapes)]
+    T = lambda b, k: torch.from_numpy(b[k]).cuda()
+    cat = lambda k: torch.cat([T(b, k) for b in bs])
+    wo, pose = pe.estimate_multi([T(b, "img") for b in bs], cat("cloud"), cat("choose").reshape(-1, N), cat("obj").reshape(-1), 2)
+    solo = PoseEstimator(est, ref)
+    for i in (0, 13, 41, 69):
+        wo1, pose1 = solo.estimate(T(bs[i], "img"), T(bs[i], "cloud"), T(bs[i], "choose"), T(bs[i], "obj"), 2)
+        assert torch.equal(wo1, wo[i:i + 1]) and torch.equal(pose1, pose[i:i + 1]), shapes[i]
+
+
 def test_layer_taps_match_the_references_intermediates():
     """The engine's debug taps (df_net_debug_taps) against the 10 intermediates the imported reference produced for the tiny
     config (forward hooks in oracle/make_golden.py): a regression localises to a layer.  up_3 exists at the chosen pixels only."""

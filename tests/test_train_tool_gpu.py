@@ -128,3 +128,26 @@ def test_two_rank_trainer_with_a_dataset_that_does_not_divide(tmp_path):
     assert out.returncode == 0, out.stdout[-3000:]
     # rank 0 logs at INFO: 15 // (2 * 4) = 1 optimizer step per epoch, two epochs
     assert out.stdout.count("Train time") == 2 and out.stdout.count("TEST FINISH") == 2, out.stdout[-3000:]
+
+
+def test_two_rank_resume_of_the_estimator_alone_keeps_the_refiners_in_sync(tmp_path):
+    """--resume_posenet without --resume_refinenet on two ranks (the usual way into the refiner phase): every rank loads the same
+    PoseNet but builds its own refiner under a per-rank seed, so the fresh network must still be broadcast -- the trainer checks the
+    replicas (train_utils.replicas_in_sync) and refuses to start otherwise."""
+    import socket
+    import subprocess
+    from densefusion_amd import synth
+    os.makedirs(tmp_path / "models", exist_ok=True)
+    torch.save({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.posenet_spec(2), 5).items()}, tmp_path / "models" / "p.pth")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, DF_TRAIN_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "train.py"), "--dist_backend", "gloo", "--dataset", "synthetic",
+           "--num_objects", "2", "--num_points", "64", "--synthetic_train_frames", "8", "--synthetic_test_frames", "2", "--batch_size", "2",
+           "--nepoch", "2", "--resume_posenet", "p.pth", "--refine_margin", "1e9", "--decay_margin", "-1", "--outf", str(tmp_path / "models"),
+           "--log_dir", str(tmp_path / "logs")]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert "different weights" not in out.stdout and out.stdout.count("TEST FINISH") >= 1, out.stdout[-3000:]

@@ -92,3 +92,34 @@ def test_flat_adam_matches_torch_optim_adam():
     p0 = flat.data.clone()
     adam.step(grad_scale=0.25)
     assert not torch.equal(p0, flat.data)
+
+
+def _sync_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                       # what tools/train.py does: per-rank seeds -> per-rank initial weights
+    a, b = nn.Linear(4, 3), nn.Linear(3, 2)
+    apart = train_utils.replicas_in_sync([a, b])
+    for prm in a.parameters():
+        dist.broadcast(prm.data, 0)
+    half = train_utils.replicas_in_sync([a, b])          # only one of the two networks was synchronised
+    for prm in b.parameters():
+        dist.broadcast(prm.data, 0)
+    ret[rank] = (apart, half, train_utils.replicas_in_sync([a, b]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_in_sync_gloo_world2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert dict(ret) == {0: (False, False, True), 1: (False, False, True)}

@@ -155,9 +155,11 @@ def main(argv=None):
     dataset, test_dataset = make_datasets(opt)
     estimator = PoseNet(num_points=opt.num_points, num_obj=opt.num_objects).to(dev)
     refiner = PoseRefineNet(num_points=opt.num_points, num_obj=opt.num_objects).to(dev)
-    if world > 1 and not opt.resume_posenet:
-        # data-parallel replicas must start from the same weights: rank 0's initialisation goes to everybody
-        for prm in list(estimator.parameters()) + list(refiner.parameters()):
+    if world > 1:
+        # data-parallel replicas must start from the same weights: rank 0's initialisation goes to everybody, decided PER
+        # NETWORK -- a run resumed from a PoseNet checkpoint alone still builds a fresh refiner on every rank
+        fresh = ([] if opt.resume_posenet else list(estimator.parameters())) + ([] if opt.resume_refinenet else list(refiner.parameters()))
+        for prm in fresh:
             buf = prm.data if opt.dist_backend == "nccl" else prm.data.cpu()
             dist.broadcast(buf, 0)
             if opt.dist_backend != "nccl":
@@ -166,6 +168,9 @@ def main(argv=None):
         estimator.load_state_dict(torch.load(os.path.join(opt.outf, opt.resume_posenet), map_location=dev, weights_only=True))
     if opt.resume_refinenet:
         refiner.load_state_dict(torch.load(os.path.join(opt.outf, opt.resume_refinenet), map_location=dev, weights_only=True))
+
+    if not train_utils.replicas_in_sync([estimator, refiner]):
+        raise RuntimeError("data-parallel ranks hold different weights after initialisation / resume")
 
     def optimizer_for(module):
         flat = train_utils.FlatParams(module)
