@@ -209,11 +209,13 @@ static int load_param(Net &n, const std::string &key, const float *src, int64_t 
       hipDeviceSynchronize();
       hipFree(tmp);
     }
-    if (e == hipSuccess && key.find("feats.layer") != std::string::npos && HW == 9 && I >= 256 && I % 4 == 0 && O % 4 == 0) {
-      // stride-1 3x3 convs of layer3 / layer4 may run in the Winograd domain: transformed copy [16][O][I] (fp64 math)
-      float *U = dev_alloc(n, key + ".wino", (size_t)16 * O * I);
-      if (!U) return set_error(DF_ERR_LAUNCH, "load_param: hipMalloc failed");
-      launch_wino_weight(dst, U, O, I, 0);
+    if (e == hipSuccess && key.find("feats.layer") != std::string::npos && HW == 9 && I >= 128 && I % 4 == 0 && O % 4 == 0) {
+      // stride-1 3x3 convs of layer2 .. layer4 may run in the Winograd domain (wino_route decides per map size): transformed copies
+      // [16][O][I] for F(2x2,3x3) and [36][O][I] for F(4x4,3x3), fp64 math
+      float *U = dev_alloc(n, key + ".wino", (size_t)16 * O * I), *U4 = dev_alloc(n, key + ".wino4", (size_t)36 * O * I);
+      if (!U || !U4) return set_error(DF_ERR_LAUNCH, "load_param: hipMalloc failed");
+      launch_wino_weight(dst, U, O, I, 0, 2);
+      launch_wino_weight(dst, U4, O, I, 0, 4);
       hipDeviceSynchronize();
     }
     if (e == hipSuccess && (key.find(".up_1.") != std::string::npos || key.find(".up_2.") != std::string::npos) && HW == 9) {
@@ -375,25 +377,13 @@ struct Ctx {
 static ConvParams point_gemm(const float *in, int in_ld, int in_coff, int cin, const float *w, const float *bias,
                              float *out, int out_ld, int out_coff, int cout, int rows, int act);
 
-static bool wino_enabled() {
-  static const bool on = getenv("DF_NO_WINOGRAD") == nullptr;      // dev switch: A/B against the direct convolution
-  return on;
-}
-
-// 3x3 stride-1 pad=dil conv (+ residual, ReLU) as input transform -> 16 batched GEMMs -> output transform.
-// V / M scratch is taken from the workspace per call; the bump allocator position is restored afterwards so that
-// consecutive layers reuse the same (cache-resident) region.
-static void wino_conv(Ctx &c, const float *x, int B, int H, int W, int cin, int x_ld, const std::string &wkey, float *out, int cout,
-                      int out_ld, int out_coff, int dil, const float *res, int res_ld, int act) {
-  const WinoGeom g = wino_geom(B, H, W, dil);
-  const size_t mark = c.off;
-  float *V = c.f((size_t)16 * g.T * cin), *M = c.f((size_t)16 * g.T * cout);
-  if (c.live()) launch_wino_input(x, x_ld, 0, V, B, H, W, cin, dil, c.st);
-  ConvParams p = point_gemm(V, cin, 0, cin, c.w(wkey + ".wino"), nullptr, M, cout, 0, cout, (int)g.T, ACT_NONE);
-  p.zcount = 16; p.z_in_coff = g.T * cin; p.z_wgt = (long)cout * cin; p.z_out_coff = g.T * cout;
-  c.conv(p);
-  if (c.live()) launch_wino_output(M, out, out_ld, out_coff, nullptr, res, res_ld, 0, act, B, H, W, cout, dil, c.st);
-  c.off = mark;
+// dev switches (A/B runs): DF_NO_WINOGRAD = direct convolutions only, DF_WINOGRAD_TILE = 2 keeps F(2x2,3x3) where a Winograd route pays
+static int wino_route_for(int H, int W, int dil, int ci, int co) {
+  static const bool off = getenv("DF_NO_WINOGRAD") != nullptr;
+  static const int force = getenv("DF_WINOGRAD_TILE") ? atoi(getenv("DF_WINOGRAD_TILE")) : 0;
+  if (off) return 0;
+  const int r = wino_route(H, W, dil, ci, co);
+  return (r && force == 2) ? 2 : r;
 }
 
 static ConvParams point_gemm(const float *in, int in_ld, int in_coff, int cin, const float *w, const float *bias,
@@ -471,36 +461,40 @@ static float *cnn_forward(Ctx &c, const std::vector<Grp> &gs, Level &half_lv) {
   // GEMM over the concatenation of their tiles (per-bucket transforms around it); the others run the direct implicit GEMM
   auto conv3x3 = [&](const float *in, const Level &li, int ci, const std::string &key, float *out, const Level &lo, int co, int stride, int dil,
                      const float *res) {
-    std::vector<int> ws;
+    std::vector<int> ws[2];        // buckets on the F(2x2) / F(4x4) route
     for (int i = 0; i < nb; ++i) {
-      if (wino_enabled() && stride == 1 && wino_pays(li.h[i], li.w[i], dil, ci, co)) { ws.push_back(i); continue; }
+      const int route = stride == 1 ? wino_route_for(li.h[i], li.w[i], dil, ci, co) : 0;
+      if (route) { ws[route == 4].push_back(i); continue; }
       ConvParams p = conv2d(in + li.off[i] * ci, gs[i].B, li.h[i], li.w[i], ci, ci, c.w(key), nullptr, out + lo.off[i] * co, lo.h[i], lo.w[i], co,
                             co, 0, 3, stride, dil, dil, ACT_RELU);
       if (res) { p.res = res + lo.off[i] * co; p.res_ld = co; }
       c.conv(p);
     }
-    if (ws.empty()) return;
-    std::vector<long> t0;
-    long T = 0;
-    for (int i : ws) { t0.push_back(T); T += wino_geom(gs[i].B, li.h[i], li.w[i], dil).T; }
-    const size_t mark = c.off;       // V / M are scratch: consecutive layers reuse the same region
-    float *V = c.f((size_t)16 * T * ci), *M = c.f((size_t)16 * T * co);
-    for (size_t j = 0; j < ws.size(); ++j) {
-      const int i = ws[j];
-      if (c.live()) launch_wino_input(in + li.off[i] * ci, ci, 0, V, gs[i].B, li.h[i], li.w[i], ci, dil, c.st, T, t0[j]);
+    for (int r = 0; r < 2; ++r) {
+      if (ws[r].empty()) continue;
+      const int m = r ? 4 : 2, nz = (m + 2) * (m + 2);
+      std::vector<long> t0;
+      long T = 0;
+      for (int i : ws[r]) { t0.push_back(T); T += wino_geom(gs[i].B, li.h[i], li.w[i], dil, m).T; }
+      const size_t mark = c.off;       // V / M are scratch: consecutive layers reuse the same region
+      float *V = c.f((size_t)nz * T * ci), *M = c.f((size_t)nz * T * co);
+      for (size_t j = 0; j < ws[r].size(); ++j) {
+        const int i = ws[r][j];
+        if (c.live()) launch_wino_input(in + li.off[i] * ci, ci, 0, V, gs[i].B, li.h[i], li.w[i], ci, dil, c.st, T, t0[j], m);
+      }
+      ConvParams p = point_gemm(V, ci, 0, ci, c.w(key + (r ? ".wino4" : ".wino")), nullptr, M, co, 0, co, (int)T, ACT_NONE);
+      p.zcount = nz; p.z_in_coff = T * ci; p.z_wgt = (long)co * ci; p.z_out_coff = T * co;
+      double px = 0;        // output pixels the tiles are for: a tile yields m x m of them
+      for (int i : ws[r]) px += (double)gs[i].B * li.h[i] * li.w[i];
+      c.conv(p, px / ((double)(m * m) * (double)T));
+      for (size_t j = 0; j < ws[r].size(); ++j) {
+        const int i = ws[r][j];
+        if (c.live())
+          launch_wino_output(M, out + lo.off[i] * co, co, 0, nullptr, res ? res + lo.off[i] * co : nullptr, co, 0, ACT_RELU, gs[i].B, li.h[i], li.w[i],
+                             co, dil, c.st, T, t0[j], m);
+      }
+      c.off = mark;
     }
-    ConvParams p = point_gemm(V, ci, 0, ci, c.w(key + ".wino"), nullptr, M, co, 0, co, (int)T, ACT_NONE);
-    p.zcount = 16; p.z_in_coff = T * ci; p.z_wgt = (long)co * ci; p.z_out_coff = T * co;
-    double px = 0;        // output pixels the tiles are for: a tile yields 2x2 of them
-    for (int i : ws) px += (double)gs[i].B * li.h[i] * li.w[i];
-    c.conv(p, px / (4.0 * (double)T));
-    for (size_t j = 0; j < ws.size(); ++j) {
-      const int i = ws[j];
-      if (c.live())
-        launch_wino_output(M, out + lo.off[i] * co, co, 0, nullptr, res ? res + lo.off[i] * co : nullptr, co, 0, ACT_RELU, gs[i].B, li.h[i], li.w[i], co,
-                           dil, c.st, T, t0[j]);
-    }
-    c.off = mark;
   };
 
   Level lx = l1;
@@ -1043,8 +1037,8 @@ extern "C" int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream) {
   return launch_conv(p, to_stream(stream));
 }
 
-// 3x3 stride-1 pad=dil convolution through the Winograd F(2x2,3x3) domain (wino.hip): weight transform, input
-// transform, 16 batched GEMMs, output transform (+ bias, residual, ReLU).  scratch holds U | V | M.
+// 3x3 stride-1 pad=dil convolution through the Winograd F(2x2,3x3) / F(4x4,3x3) domain (wino.hip): weight transform, input
+// transform, 16 / 36 batched GEMMs, output transform (+ bias, residual, ReLU).  scratch holds U | V | M.
 static int wino_desc_ok(const df_conv_desc *d, const char *what) {
   if (!d) return set_error(DF_ERR_ARG, "%s: null descriptor", what);
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != d->dil || d->dil < 1)
@@ -1056,30 +1050,41 @@ static int wino_desc_ok(const df_conv_desc *d, const char *what) {
   return DF_OK;
 }
 
-extern "C" size_t df_conv3x3_winograd_scratch_bytes(const df_conv_desc *d) {
+extern "C" size_t df_conv3x3_winograd_tile_scratch_bytes(const df_conv_desc *d, int tile) {
   if (wino_desc_ok(d, "conv3x3_winograd_scratch_bytes") != DF_OK) return 0;
-  const WinoGeom g = wino_geom(d->B, d->H, d->W, d->dil);
-  return ((size_t)16 * d->Cout * d->Cin + (size_t)16 * g.T * d->Cin + (size_t)16 * g.T * d->Cout) * sizeof(float);
+  if (tile != 2 && tile != 4) { set_error(DF_ERR_ARG, "conv3x3_winograd: tile must be 2 or 4"); return 0; }
+  const WinoGeom g = wino_geom(d->B, d->H, d->W, d->dil, tile);
+  const size_t nz = (size_t)(tile + 2) * (tile + 2);
+  return (nz * d->Cout * d->Cin + nz * g.T * d->Cin + nz * g.T * d->Cout) * sizeof(float);
 }
 
-extern "C" int df_conv3x3_winograd_nhwc(const df_conv_desc *d, void *scratch, size_t scratch_bytes, df_stream_t stream) {
+extern "C" int df_conv3x3_winograd_tile_nhwc(const df_conv_desc *d, int tile, void *scratch, size_t scratch_bytes, df_stream_t stream) {
   int rc = wino_desc_ok(d, "conv3x3_winograd_nhwc");
   if (rc != DF_OK) return rc;
+  if (tile != 2 && tile != 4) return set_error(DF_ERR_ARG, "conv3x3_winograd: tile must be 2 or 4");
   if (!d->in || !d->wgt || !d->out || !scratch) return set_error(DF_ERR_ARG, "conv3x3_winograd_nhwc: null pointer");
-  if (scratch_bytes < df_conv3x3_winograd_scratch_bytes(d)) return set_error(DF_ERR_WORKSPACE, "conv3x3_winograd_nhwc: scratch too small");
-  const WinoGeom g = wino_geom(d->B, d->H, d->W, d->dil);
+  if (scratch_bytes < df_conv3x3_winograd_tile_scratch_bytes(d, tile)) return set_error(DF_ERR_WORKSPACE, "conv3x3_winograd_nhwc: scratch too small");
+  const WinoGeom g = wino_geom(d->B, d->H, d->W, d->dil, tile);
+  const int nz = (tile + 2) * (tile + 2);
   hipStream_t st = to_stream(stream);
-  float *U = static_cast<float *>(scratch), *V = U + (size_t)16 * d->Cout * d->Cin, *M = V + (size_t)16 * g.T * d->Cin;
-  launch_wino_weight(d->wgt, U, d->Cout, d->Cin, st);
-  launch_wino_input(d->in, d->in_ld, d->in_coff, V, d->B, d->H, d->W, d->Cin, d->dil, st);
+  float *U = static_cast<float *>(scratch), *V = U + (size_t)nz * d->Cout * d->Cin, *M = V + (size_t)nz * g.T * d->Cin;
+  launch_wino_weight(d->wgt, U, d->Cout, d->Cin, st, tile);
+  launch_wino_input(d->in, d->in_ld, d->in_coff, V, d->B, d->H, d->W, d->Cin, d->dil, st, 0, 0, tile);
   ConvParams p;
   p.in = V; p.wgt = U; p.out = M;
   p.B = (int)g.T; p.Cin = d->Cin; p.in_ld = d->Cin; p.Cout = d->Cout; p.out_ld = d->Cout;
-  p.zcount = 16; p.z_in_coff = g.T * d->Cin; p.z_wgt = (long)d->Cout * d->Cin; p.z_out_coff = g.T * d->Cout;
+  p.zcount = nz; p.z_in_coff = g.T * d->Cin; p.z_wgt = (long)d->Cout * d->Cin; p.z_out_coff = g.T * d->Cout;
   rc = launch_conv(p, st);
   if (rc != DF_OK) return rc;
-  launch_wino_output(M, d->out, d->out_ld, d->out_coff, d->bias, d->res, d->res_ld, d->res_coff, d->act, d->B, d->H, d->W, d->Cout, d->dil, st);
+  launch_wino_output(M, d->out, d->out_ld, d->out_coff, d->bias, d->res, d->res_ld, d->res_coff, d->act, d->B, d->H, d->W, d->Cout, d->dil, st, 0, 0,
+                     tile);
   return check_launch("conv3x3_winograd_nhwc");
+}
+
+extern "C" size_t df_conv3x3_winograd_scratch_bytes(const df_conv_desc *d) { return df_conv3x3_winograd_tile_scratch_bytes(d, 2); }
+
+extern "C" int df_conv3x3_winograd_nhwc(const df_conv_desc *d, void *scratch, size_t scratch_bytes, df_stream_t stream) {
+  return df_conv3x3_winograd_tile_nhwc(d, 2, scratch, scratch_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

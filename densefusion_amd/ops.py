@@ -91,9 +91,9 @@ def wgrad(d, dy, dw, db):
                                       ws.data_ptr(), ws.numel(), _lib.current_stream()), "conv2d_wgrad")
 
 
-def conv3x3_winograd_nhwc(x, w, bias=None, dil=1, act=0, res=None):
-    """3x3 / stride 1 / pad == dil convolution through the Winograd F(2x2,3x3) domain (``df_conv3x3_winograd_nhwc``).
-    x [B,H,W,Cin], w [Cout,3,3,Cin] -> [B,H,W,Cout]."""
+def conv3x3_winograd_nhwc(x, w, bias=None, dil=1, act=0, res=None, tile=2):
+    """3x3 / stride 1 / pad == dil convolution through the Winograd F(tile x tile, 3x3) domain, tile 2 or 4
+    (``df_conv3x3_winograd_tile_nhwc``).  x [B,H,W,Cin], w [Cout,3,3,Cin] -> [B,H,W,Cout]."""
     B, H, W, in_ld = x.shape
     Cout, KH, KW, Cin = w.shape
     out = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.float32)
@@ -108,9 +108,9 @@ def conv3x3_winograd_nhwc(x, w, bias=None, dil=1, act=0, res=None):
     d.KH, d.KW, d.stride, d.pad, d.dil, d.act = KH, KW, 1, dil, dil, act
     L = _lib.lib()
     with _lib.device_guard(x.device):
-        need = L.df_conv3x3_winograd_scratch_bytes(ctypes.byref(d))
+        need = L.df_conv3x3_winograd_tile_scratch_bytes(ctypes.byref(d), tile)
         if need == 0:
             _lib.check(-1, "conv3x3_winograd_scratch_bytes")
         scratch = torch.empty(int(need), dtype=torch.uint8, device=x.device)
-        _lib.check(L.df_conv3x3_winograd_nhwc(ctypes.byref(d), scratch.data_ptr(), need, _lib.current_stream()), "conv3x3_winograd_nhwc")
+        _lib.check(L.df_conv3x3_winograd_tile_nhwc(ctypes.byref(d), tile, scratch.data_ptr(), need, _lib.current_stream()), "conv3x3_winograd_nhwc")
     return out

@@ -225,6 +225,12 @@ int df_conv_splitk_scratch(void *ptr, size_t bytes);
  * activations; results differ from df_conv2d_nhwc by fp32 re-association only. */
 size_t df_conv3x3_winograd_scratch_bytes(const df_conv_desc *d);
 int df_conv3x3_winograd_nhwc(const df_conv_desc *d, void *scratch, size_t scratch_bytes, df_stream_t stream);
+/* The same with the output tile chosen: tile = 2 is the call above; tile = 4 is F(4x4,3x3) on the interpolation points
+ * {0, 1, -1, 1/2, -2, inf}: 36 multiplies per 4x4 outputs (2.25 per output), transformed activations 2.25x the map instead of 4x;
+ * rounding error ~4x that of tile 2 per layer (tests/test_conv_gpu.py), invisible in the selected pose.  The
+ * engine picks direct / 2 / 4 per layer and map size from a cost estimate that depends on the layer geometry only. */
+size_t df_conv3x3_winograd_tile_scratch_bytes(const df_conv_desc *d, int tile);
+int df_conv3x3_winograd_tile_nhwc(const df_conv_desc *d, int tile, void *scratch, size_t scratch_bytes, df_stream_t stream);
 /* Gradients of df_conv2d_nhwc (training path; `d` describes the FORWARD convolution, d->wgt = its weights):
  *   dgrad: dx[b][iy][ix][in_coff + c] (+)= sum dy[b][oy][ox][out_coff + n] * wgt[n][ky][kx][c] over the taps/outputs that
  *          read that input pixel; runs on the same MFMA kernel as the forward pass on flipped, transposed weights
