@@ -67,6 +67,7 @@ SIGNATURES = {
     "df_conv_splitk_scratch": (_i, [_vp, _sz]),
     "df_conv3x3_winograd_scratch_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "df_conv3x3_winograd_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, ctypes.c_size_t, _vp]),
+    "df_wino_route": (_i, [_i, _i, _i, _i, _i]),
     "df_conv3x3_winograd_tile_scratch_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc), _i]),
     "df_conv3x3_winograd_tile_nhwc": (_i, [ctypes.POINTER(ConvDesc), _i, _vp, ctypes.c_size_t, _vp]),
     "df_conv2d_dgrad_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),

@@ -1081,6 +1081,8 @@ extern "C" int df_conv3x3_winograd_tile_nhwc(const df_conv_desc *d, int tile, vo
   return check_launch("conv3x3_winograd_nhwc");
 }
 
+extern "C" int df_wino_route(int H, int W, int dil, int Cin, int Cout) { return wino_route(H, W, dil, Cin, Cout); }
+
 extern "C" size_t df_conv3x3_winograd_scratch_bytes(const df_conv_desc *d) { return df_conv3x3_winograd_tile_scratch_bytes(d, 2); }
 
 extern "C" int df_conv3x3_winograd_nhwc(const df_conv_desc *d, void *scratch, size_t scratch_bytes, df_stream_t stream) {

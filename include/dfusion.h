@@ -229,6 +229,7 @@ int df_conv3x3_winograd_nhwc(const df_conv_desc *d, void *scratch, size_t scratc
  * {0, 1, -1, 1/2, -2, inf}: 36 multiplies per 4x4 outputs (2.25 per output), transformed activations 2.25x the map instead of 4x;
  * rounding error ~4x that of tile 2 per layer (tests/test_conv_gpu.py), invisible in the selected pose.  The
  * engine picks direct / 2 / 4 per layer and map size from a cost estimate that depends on the layer geometry only. */
+int df_wino_route(int H, int W, int dil, int Cin, int Cout);   /* the engine's choice for an H x W map: 0 direct, 2, 4 (host only) */
 size_t df_conv3x3_winograd_tile_scratch_bytes(const df_conv_desc *d, int tile);
 int df_conv3x3_winograd_tile_nhwc(const df_conv_desc *d, int tile, void *scratch, size_t scratch_bytes, df_stream_t stream);
 /* Gradients of df_conv2d_nhwc (training path; `d` describes the FORWARD convolution, d->wgt = its weights):

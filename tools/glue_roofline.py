@@ -17,13 +17,15 @@ HBM = bench.HBM_PEAK_GBS
 N, NPAD, PER, ITERS = bench.N_PTS, 1024, 40, bench.ITERS
 
 
-def wino_geom(H, W, d):
-    TH, TW = ((H + d - 1) // d + 1) // 2, ((W + d - 1) // d + 1) // 2
+def wino_geom(H, W, d, m):
+    TH, TW = ((H + d - 1) // d + m - 1) // m, ((W + d - 1) // d + m - 1) // m
     return d * d * TH * TW
 
 
-def wino_pays(H, W, d, cin):
-    return cin >= 256 and 16.0 * wino_geom(H, W, d) <= 0.72 * 9.0 * H * W
+def wino_route(H, W, d, cin, cout):
+    """the engine's own decision (csrc/wino.hip wino_route): 0 direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3)"""
+    from densefusion_amd import _lib
+    return _lib.lib().df_wino_route(H, W, d, cin, cout)
 
 
 def step_bytes():
@@ -36,14 +38,17 @@ def step_bytes():
         h, w = H // 8, W // 8              # layer2..4, psp
         add("nchw3_to_nhwc4_kernel", B * (3 + 4) * H * W * 4)
         add("maxpool3s2_kernel", B * (h2 * w2 + h4 * w4) * 64 * 4)
-        # Winograd-domain convs (engine.hip cnn_forward): (cin, cout, dil, residual)
-        for cin, cout, d, res in ((256, 256, 1, True), (256, 256, 2, False), (256, 256, 2, True), (256, 512, 1, False), (512, 512, 1, True),
+        # stride-1 3x3 convs that may take a Winograd route (engine.hip cnn_forward): (cin, cout, dil, residual)
+        for cin, cout, d, res in ((128, 128, 1, True), (128, 128, 1, False), (128, 128, 1, True), (128, 256, 1, False), (256, 256, 1, True),
+                                  (256, 256, 2, False), (256, 256, 2, True), (256, 512, 1, False), (512, 512, 1, True),
                                   (512, 512, 4, False), (512, 512, 4, True)):
-            if not wino_pays(h, w, d, cin):
+            m = wino_route(h, w, d, cin, cout)
+            if not m:
                 continue
-            T = wino_geom(h, w, d)
-            add("wino_input_kernel", B * (h * w * cin + 16 * T * cin) * 4)
-            add("wino_output_kernel", B * (16 * T * cout + h * w * cout * (2 if res else 1)) * 4)
+            T, nz = wino_geom(h, w, d, m), (m + 2) ** 2
+            k = "wino_" if m == 2 else "wino4_"
+            add(k + "input_kernel", B * (h * w * cin + nz * T * cin) * 4)
+            add(k + "output_kernel", B * (nz * T * cout + h * w * cout * (2 if res else 1)) * 4)
         add("psp_pool_kernel", B * (h * w * 512 + 50 * 512) * 4)
         add("psp_prior_sum_kernel", B * (50 * 1024 + h * w * 1024) * 4)
         add("upconv_gather_tiled_kernel", B * (h * w * 9 * 256 + 4 * h * w * 256) * 4)          # up_1
@@ -67,7 +72,7 @@ def main():
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
             for k in alg:
-                if k in r["Name"]:
+                if k + "(" in r["Name"] or k + "<" in r["Name"] or r["Name"].endswith(k):
                     us = int(r["TotalDurationNs"]) / passes / 1e3
                     gbs = alg[k] / us / 1e3
                     rows.append({"kernel": k, "calls_per_step": round(int(r["Calls"]) / passes, 1), "us_per_step": round(us, 1),
