@@ -68,6 +68,17 @@ SIGNATURES = {
     "df_conv3x3_winograd_scratch_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "df_conv3x3_winograd_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, ctypes.c_size_t, _vp]),
     "df_wino_route": (_i, [_i, _i, _i, _i, _i]),
+    "df_trainer_create": (_vp, [_i, _i, _i]),
+    "df_trainer_destroy": (None, [_vp]),
+    "df_trainer_flat_numel": (_i64, [_vp]),
+    "df_trainer_num_params": (_i, [_vp]),
+    "df_trainer_param_info": (_i, [_vp, _i, ctypes.c_char_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i)]),
+    "df_trainer_pack_param": (_i, [_vp, ctypes.c_char_p, _vp, _vp, _vp]),
+    "df_trainer_unpack_param": (_i, [_vp, ctypes.c_char_p, _vp, _vp, _vp]),
+    "df_posenet_train_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "df_posenet_train_step": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _f, _i, ctypes.c_uint] + [_vp] * 9 + [_sz, _vp]),
+    "df_refiner_train_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "df_refiner_train_step": (_i, [_vp, _vp, _vp, _i64, _i] + [_vp] * 5 + [_i, _vp] + [_vp] * 4 + [_sz, _vp]),
     "df_conv3x3_winograd_tile_scratch_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc), _i]),
     "df_conv3x3_winograd_tile_nhwc": (_i, [ctypes.POINTER(ConvDesc), _i, _vp, ctypes.c_size_t, _vp]),
     "df_conv2d_dgrad_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),

@@ -61,6 +61,7 @@ int launch_conv(const ConvParams &p, hipStream_t st);
 // dw / db (optional: column sums of dY) are overwritten.  The pixel range is split over workgroups; the partial tiles go to `ws`
 // (wgrad_workspace_bytes) and are added in a fixed order: bit-reproducible, no atomics.
 size_t wgrad_workspace_bytes(const ConvParams &p);
-int launch_wgrad(const ConvParams &p, float *dw, float *db, void *ws, size_t ws_bytes, hipStream_t st);
+// accumulate != 0: dw / db += this launch's gradient (accumulation over the frames of an optimizer step)
+int launch_wgrad(const ConvParams &p, float *dw, float *db, void *ws, size_t ws_bytes, hipStream_t st, int accumulate = 0);
 
 }  // namespace df

@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_v2_kernel(const ConvParams p, f
 // dw[i] = sum_z part[z][i], bit-reproducible: 8 z-lanes per output vector each add their slices z = l, l + 8, ... in ascending
 // order (8 independent load chains instead of one of length `split`), then the 8 partial sums meet in LDS and are added in
 // lane order.  32 float4 outputs per workgroup.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, long n4, int split) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, long n4, int split, int accumulate) {
   __shared__ f32x4 s_p[8][32];
   const int col = threadIdx.x & 31, zl = threadIdx.x >> 5;
   for (long i0 = blockIdx.x * 32L; i0 < n4; i0 += (long)gridDim.x * 32) {
@@ -1171,6 +1171,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
       for (int l = 1; l < 8; ++l)
 #pragma unroll
         for (int e = 0; e < 4; ++e) a[e] += s_p[l][col][e];
+      if (accumulate) {                      // dw += this launch's sum (gradient accumulation over passes: still one fixed order)
+        const f32x4 old = reinterpret_cast<const f32x4 *>(dw)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = old[e] + a[e];
+      }
       reinterpret_cast<f32x4 *>(dw)[i] = a;
     }
     __syncthreads();
@@ -1192,7 +1197,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float *__restrict_
 }
 
 // db[c] = sum_b part[b][c]: 8 lanes per channel add b = l, l + 8, ... in ascending order, then meet in LDS in lane order
-__global__ __launch_bounds__(256) void bias_reduce_kernel(const float *__restrict__ part, float *__restrict__ db, int C, int nblk) {
+__global__ __launch_bounds__(256) void bias_reduce_kernel(const float *__restrict__ part, float *__restrict__ db, int C, int nblk, int accumulate) {
   __shared__ float s_p[8][32];
   const int col = threadIdx.x & 31, zl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + col;
@@ -1204,7 +1209,7 @@ __global__ __launch_bounds__(256) void bias_reduce_kernel(const float *__restric
   if (zl == 0 && c < C) {
 #pragma unroll
     for (int l = 1; l < 8; ++l) a += s_p[l][col];
-    db[c] = a;
+    db[c] = accumulate ? db[c] + a : a;
   }
 }
 
@@ -1399,7 +1404,7 @@ WgradPlan wgrad_plan(const ConvParams &p) {
   w.chunk = ((M + split - 1) / split + 31) / 32 * 32;
   w.split = (M + w.chunk - 1) / w.chunk;
   w.nblk = (M + 127) / 128;
-  w.part_floats = w.split > 1 ? (size_t)w.split * p.Cout * K : 0;       // a single slice goes straight to dw
+  w.part_floats = (size_t)w.split * p.Cout * K;       // (a single slice goes straight to dw unless the launch accumulates)
   w.bias_floats = (size_t)w.nblk * p.Cout;
   return w;
 }
@@ -1410,7 +1415,7 @@ size_t wgrad_workspace_bytes(const ConvParams &p) {
   return (w.part_floats + w.bias_floats) * sizeof(float);
 }
 
-int launch_wgrad(const ConvParams &p0, float *dw, float *db, void *ws, size_t ws_bytes, hipStream_t st) {
+int launch_wgrad(const ConvParams &p0, float *dw, float *db, void *ws, size_t ws_bytes, hipStream_t st, int accumulate) {
   ConvParams p = p0;
   if (!p.in || !p.out || !dw) return set_error(DF_ERR_ARG, "wgrad: null pointer");
   if (p.Cin % 4 || p.in_ld % 4 || p.in_coff % 4 || p.out_ld % 4 || p.out_coff % 4 || p.Cout % 4)
@@ -1422,7 +1427,8 @@ int launch_wgrad(const ConvParams &p0, float *dw, float *db, void *ws, size_t ws
     return set_error(DF_ERR_ARG, "wgrad: tensor too large (4 GB per operand)");
   const WgradPlan w = wgrad_plan(p);
   if (wgrad_workspace_bytes(p) > ws_bytes || (wgrad_workspace_bytes(p) && !ws)) return set_error(DF_ERR_WORKSPACE, "wgrad: workspace too small");
-  float *part = w.split > 1 ? static_cast<float *>(ws) : dw;
+  const bool reduce = w.split > 1 || accumulate;
+  float *part = reduce ? static_cast<float *>(ws) : dw;
   float *bpart = static_cast<float *>(ws) + w.part_floats;
   make_fdiv((long)p.OH * p.OW, p.ohw_magic, p.ohw_sh);
   make_fdiv(p.OW, p.ow_magic, p.ow_sh);
@@ -1440,13 +1446,13 @@ int launch_wgrad(const ConvParams &p0, float *dw, float *db, void *ws, size_t ws
   } else {
     hipLaunchKernelGGL(wgrad_f32_kernel, dim3(w.tiles, 1, w.split), dim3(256), 0, st, p, part, w.chunk);
   }
-  if (w.split > 1) {
+  if (reduce) {
     const long n4 = (long)p.Cout * K / 4;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((n4 + 31) / 32, 8192)), dim3(256), 0, st, part, dw, n4, w.split);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((n4 + 31) / 32, 8192)), dim3(256), 0, st, part, dw, n4, w.split, accumulate);
   }
   if (db) {
     hipLaunchKernelGGL(bias_grad_kernel, dim3((p.Cout + 63) / 64, w.nblk), dim3(256), 0, st, p.out, M, p.Cout, p.out_ld, p.out_coff, bpart, 128);
-    hipLaunchKernelGGL(bias_reduce_kernel, dim3((p.Cout + 31) / 32), dim3(256), 0, st, bpart, db, p.Cout, w.nblk);
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3((p.Cout + 31) / 32), dim3(256), 0, st, bpart, db, p.Cout, w.nblk, accumulate);
   }
   return check_launch("wgrad");
 }

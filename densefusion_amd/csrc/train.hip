@@ -1,0 +1,1518 @@
+// Native training step of PoseNet / PoseRefineNet (tools/train.py:131-176 of the reference): forward, loss and backward of B same-size
+// frames sequenced in C++ on one stream -- no host synchronisation, no allocation, every launch capturable in a hipGraph.
+//
+//   * parameters and gradients live in ONE flat fp32 buffer each, in KERNEL layout (conv O(HW)I, up_1 / up_2 tap-major, head layer 1
+//     split into its per-point and global-feature column blocks, the three head towers stacked): the caller owns both buffers
+//     (Adam and the gradient all-reduce are layout-agnostic); df_trainer_pack_param / _unpack_param convert to and from the
+//     reference's state-dict layout, so checkpoints keep the reference's keys and shapes (tools/train.py:172-176).
+//   * gradients are ACCUMULATED into the flat gradient buffer (the reference's `loss.backward()` per frame, `optimizer.step()`
+//     every batch_size frames, tools/train.py:161-169); every reduction has a fixed order -- no float atomics anywhere: two
+//     identical steps give bit-identical gradient buffers.
+//   * the forward half keeps the exact rewrites of the inference engine that have a cheap adjoint: concatenations written in
+//     place (channel offsets), the global-feature fold of head layer 1, up_1 / up_2 as low-resolution per-tap products followed by
+//     the 9-tap interpolation, up_3 + final 1x1 + LogSoftmax only at the chosen pixels, the last head layer only for the frame's
+//     object (lib/network.py:119-131: the other objects' rows receive no gradient in the reference either).
+//
+// Reference lines mirrored: lib/extractors.py:29-43,114-124; lib/pspnet.py:20-24,27-37,64-77; lib/network.py:53-68,95-132,151-206;
+// lib/loss.py:13-70; lib/loss_refiner.py:12-62.
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "igemm.h"
+#include "layers.h"
+
+namespace df {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int TB = 256;
+inline unsigned nblk(long n, long cap = 16384) { long b = (n + TB - 1) / TB; return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b)); }
+#define GRID_STRIDE(i, n) for (long i = blockIdx.x * (long)TB + threadIdx.x; i < (n); i += (long)gridDim.x * TB)
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline int conv_out(int in, int k, int stride, int pad, int dil) { return (in + 2 * pad - dil * (k - 1) - 1) / stride + 1; }
+
+// ------------------------------------------------------------------------------------------------
+// kernels (the glue between the MFMA launches; every sum in a fixed order)
+// ------------------------------------------------------------------------------------------------
+
+// g <- g * act'(y) in place on a [rows][C] view; PReLU (act 2) also leaves per-workgroup partial sums of dslope in `part`
+__global__ __launch_bounds__(TB) void act_bwd2d_kernel(float *__restrict__ g, int g_ld, const float *__restrict__ y, int y_ld, long rows, int C4,
+                                                       int act, const float *__restrict__ slope_p, float *__restrict__ part) {
+  __shared__ float s_red[TB];
+  const float slope = act == 2 ? slope_p[0] : 0.f;
+  float ds = 0.f;
+  GRID_STRIDE(i, rows * C4) {
+    const long r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    f32x4 gv = *reinterpret_cast<f32x4 *>(g + r * g_ld + c);
+    const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + r * y_ld + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (!(yv[e] > 0.f)) {
+        if (act == 2) ds += gv[e] * (yv[e] / slope);        // x = y / slope on the negative side
+        gv[e] *= slope;
+      }
+    *reinterpret_cast<f32x4 *>(g + r * g_ld + c) = gv;
+  }
+  if (act == 2) {
+    s_red[threadIdx.x] = ds;
+    __syncthreads();
+    for (int d = TB / 2; d >= 1; d >>= 1) { if ((int)threadIdx.x < d) s_red[threadIdx.x] += s_red[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = s_red[0];
+  }
+}
+
+// dst[j] (+)= sum_i part[i * n + j], i ascending: one thread per output
+__global__ __launch_bounds__(TB) void sum_partials_kernel(const float *__restrict__ part, int count, long n, float *__restrict__ dst, int accumulate) {
+  GRID_STRIDE(j, n) {
+    float a = 0.f;
+    for (int i = 0; i < count; ++i) a += part[(long)i * n + j];
+    dst[j] = accumulate ? dst[j] + a : a;
+  }
+}
+
+// dst (+)= src on [rows][C] views
+__global__ __launch_bounds__(TB) void add2d_kernel(float *__restrict__ dst, int d_ld, const float *__restrict__ src, int s_ld, long rows, int C4) {
+  GRID_STRIDE(i, rows * C4) {
+    const long r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    f32x4 a = *reinterpret_cast<f32x4 *>(dst + r * d_ld + c);
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(src + r * s_ld + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] += b[e];
+    *reinterpret_cast<f32x4 *>(dst + r * d_ld + c) = a;
+  }
+}
+
+// AdaptiveAvgPool2d(s), lib/pspnet.py:16: bin i covers [floor(i*H/s), ceil((i+1)*H/s)); x is a [B*H*W][C] view
+__global__ __launch_bounds__(TB) void pool_fwd_kernel(const float *__restrict__ x, int x_ld, float *__restrict__ y, int B, int H, int W, int C4, int s) {
+  GRID_STRIDE(i, (long)B * s * s * C4) {
+    const int c = (int)(i % C4) * 4;
+    long r = i / C4;
+    const int bj = (int)(r % s); r /= s;
+    const int bi = (int)(r % s);
+    const int b = (int)(r / s);
+    const int y0 = (bi * H) / s, y1 = ((bi + 1) * H + s - 1) / s, x0 = (bj * W) / s, x1 = ((bj + 1) * W + s - 1) / s;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int yy = y0; yy < y1; ++yy)
+      for (int xx = x0; xx < x1; ++xx) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((long)(b * H + yy) * W + xx) * x_ld + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+      }
+    const float cnt = (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] /= cnt;
+    reinterpret_cast<f32x4 *>(y)[i] = acc;
+  }
+}
+__global__ __launch_bounds__(TB) void pool_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx, int dx_ld, int B, int H, int W, int C4,
+                                                      int s, int accumulate) {
+  GRID_STRIDE(i, (long)B * H * W * C4) {
+    const int c = (int)(i % C4) * 4;
+    long r = i / C4;
+    const long pix = r;
+    const int xx = (int)(r % W); r /= W;
+    const int yy = (int)(r % H);
+    const int b = (int)(r / H);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int bi = 0; bi < s; ++bi) {
+      const int y0 = (bi * H) / s, y1 = ((bi + 1) * H + s - 1) / s;
+      if (yy < y0 || yy >= y1) continue;
+      for (int bj = 0; bj < s; ++bj) {
+        const int x0 = (bj * W) / s, x1 = ((bj + 1) * W + s - 1) / s;
+        if (xx < x0 || xx >= x1) continue;
+        const f32x4 v = reinterpret_cast<const f32x4 *>(dy)[((long)(b * s + bi) * s + bj) * C4 + c / 4];
+        const float cnt = (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e] / cnt;
+      }
+    }
+    float *d = dx + pix * dx_ld + c;
+    if (accumulate) {
+      const f32x4 o = *reinterpret_cast<const f32x4 *>(d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = o[e] + acc[e];
+    }
+    *reinterpret_cast<f32x4 *>(d) = acc;
+  }
+}
+
+// bilinear source (ATen UpSample semantics, fp32): align != 0 -> src = dst*(in-1)/(out-1); else half-pixel, clamped at 0
+__device__ inline void bil_src(int dst, int in_size, int out_size, int align, int &i0, int &i1, float &l0, float &l1) {
+  float s;
+  if (align) s = (out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f) * (float)dst;
+  else { s = ((float)in_size / (float)out_size) * ((float)dst + 0.5f) - 0.5f; if (s < 0.f) s = 0.f; }
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+  l0 = 1.f - l1;
+}
+// the destination indices that may interpolate from source index q: a conservative range, every candidate is re-checked with bil_src
+__device__ inline void bil_cands(int q, int in_size, int out_size, int align, int &lo, int &hi) {
+  const float inv = align ? (in_size > 1 ? (float)(out_size - 1) / (float)(in_size - 1) : (float)out_size)
+                          : (float)out_size / (float)in_size;
+  lo = (int)floorf(((float)q - 1.f) * inv) - 2;
+  hi = (int)ceilf(((float)q + 1.5f) * inv) + 2;
+  if (lo < 0 || q == 0) lo = 0;
+  if (hi > out_size - 1 || q == in_size - 1) hi = out_size - 1;
+}
+
+// y[b][oy][ox][c] = bilinear resample of x [B][H][W][C] to (OH, OW); y is a [B*OH*OW][C] view of width y_ld
+__global__ __launch_bounds__(TB) void bilinear_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int y_ld, int B, int H, int W, int C4,
+                                                          int OH, int OW, int align) {
+  GRID_STRIDE(i, (long)B * OH * OW * C4) {
+    const int c = (int)(i % C4) * 4;
+    long r = i / C4;
+    const long pix = r;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH);
+    const int b = (int)(r / OH);
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    bil_src(oy, H, OH, align, y0, y1, wy0, wy1);
+    bil_src(ox, W, OW, align, x0, x1, wx0, wx1);
+    const float *p = x + (long)b * H * W * C4 * 4 + c;
+    const f32x4 v00 = *reinterpret_cast<const f32x4 *>(p + ((long)y0 * W + x0) * C4 * 4), v01 = *reinterpret_cast<const f32x4 *>(p + ((long)y0 * W + x1) * C4 * 4);
+    const f32x4 v10 = *reinterpret_cast<const f32x4 *>(p + ((long)y1 * W + x0) * C4 * 4), v11 = *reinterpret_cast<const f32x4 *>(p + ((long)y1 * W + x1) * C4 * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = wy0 * (wx0 * v00[e] + wx1 * v01[e]) + wy1 * (wx0 * v10[e] + wx1 * v11[e]);
+    *reinterpret_cast<f32x4 *>(y + pix * y_ld + c) = o;
+  }
+}
+// adjoint as a gather: dx[b][q] = sum over the destination pixels that read q (rows then columns ascending) of weight * dy
+__global__ __launch_bounds__(TB) void bilinear_bwd_kernel(const float *__restrict__ dy, int dy_ld, float *__restrict__ dx, int B, int H, int W, int C4,
+                                                          int OH, int OW, int align) {
+  GRID_STRIDE(i, (long)B * H * W * C4) {
+    const int c = (int)(i % C4) * 4;
+    long r = i / C4;
+    const int qx = (int)(r % W); r /= W;
+    const int qy = (int)(r % H);
+    const int b = (int)(r / H);
+    int ylo, yhi, xlo, xhi;
+    bil_cands(qy, H, OH, align, ylo, yhi);
+    bil_cands(qx, W, OW, align, xlo, xhi);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      int y0, y1;
+      float wy0, wy1;
+      bil_src(oy, H, OH, align, y0, y1, wy0, wy1);
+      const float wy = (y0 == qy ? wy0 : 0.f) + (y1 == qy ? wy1 : 0.f);
+      if (y0 != qy && y1 != qy) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        int x0, x1;
+        float wx0, wx1;
+        bil_src(ox, W, OW, align, x0, x1, wx0, wx1);
+        if (x0 != qx && x1 != qx) continue;
+        const float wx = (x0 == qx ? wx0 : 0.f) + (x1 == qx ? wx1 : 0.f);
+        const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + ((long)(b * OH + oy) * OW + ox) * dy_ld + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += (wy * wx) * g[e];
+      }
+    }
+    reinterpret_cast<f32x4 *>(dx)[i] = acc;
+  }
+}
+
+// Adjoint of layers.hip upconv_gather (PSPUpsample through the low-resolution per-tap products): g [B][2h][2w][Cout] is the
+// gradient of the pre-activation; dY[b][qy][qx][tap][c] = sum over the upsampled positions u = P + tap - 1 (inside the image) that
+// interpolate from (qy, qx) of weight(u -> q) * g[P]
+__global__ __launch_bounds__(TB) void upconv_gather_bwd_kernel(const float *__restrict__ g, float *__restrict__ dY, int B, int h, int w, int Cout) {
+  const int C4 = Cout / 4, OH = 2 * h, OW = 2 * w;
+  GRID_STRIDE(i, (long)B * h * w * 9 * C4) {
+    const int c = (int)(i % C4) * 4;
+    long r = i / C4;
+    const int tap = (int)(r % 9); r /= 9;
+    const int qx = (int)(r % w); r /= w;
+    const int qy = (int)(r % h);
+    const int b = (int)(r / h);
+    const int dy = tap / 3, dx = tap - dy * 3;
+    int ylo, yhi, xlo, xhi;
+    bil_cands(qy, h, OH, 1, ylo, yhi);
+    bil_cands(qx, w, OW, 1, xlo, xhi);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int uy = ylo; uy <= yhi; ++uy) {
+      const int py = uy - dy + 1;
+      if ((unsigned)py >= (unsigned)OH) continue;
+      int y0, y1;
+      float wy0, wy1;
+      bil_src(uy, h, OH, 1, y0, y1, wy0, wy1);
+      if (y0 != qy && y1 != qy) continue;
+      const float wy = (y0 == qy ? wy0 : 0.f) + (y1 == qy ? wy1 : 0.f);
+      for (int ux = xlo; ux <= xhi; ++ux) {
+        const int px = ux - dx + 1;
+        if ((unsigned)px >= (unsigned)OW) continue;
+        int x0, x1;
+        float wx0, wx1;
+        bil_src(ux, w, OW, 1, x0, x1, wx0, wx1);
+        if (x0 != qx && x1 != qx) continue;
+        const float wx = (x0 == qx ? wx0 : 0.f) + (x1 == qx ? wx1 : 0.f);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(g + ((long)(b * OH + py) * OW + px) * Cout + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += (wy * wx) * v[e];
+      }
+    }
+    reinterpret_cast<f32x4 *>(dY)[i] = acc;
+  }
+}
+
+// Adjoint of layers.hip up3_patch (the 3x3 patch of the bilinearly upsampled half-resolution map at every chosen pixel):
+// dU[b][qy][qx][c] = sum over points n (ascending) and taps (ascending) whose upsampled position interpolates from (qy, qx) of
+// weight * dpatch[b][n][tap][c].  A workgroup = one half-resolution row segment of one frame; the points' pixels are decoded
+// once into LDS with the range of half-resolution rows / columns their patch can touch, so a thread rejects most points on
+// two comparisons.
+constexpr int U3_PTS = 2048;
+__global__ __launch_bounds__(TB) void up3_patch_bwd_kernel(const float *__restrict__ dpatch, const int64_t *__restrict__ choose, float *__restrict__ dU,
+                                                           int h, int wd, int N, int Npad) {
+  __shared__ short s_py[U3_PTS], s_px[U3_PTS], s_rlo[U3_PTS], s_rhi[U3_PTS], s_clo[U3_PTS], s_chi[U3_PTS];
+  const int OH = 2 * h, OW = 2 * wd, HW = OH * OW;
+  const int b = blockIdx.z, qy = blockIdx.y;
+  const int c4 = threadIdx.x & 15, qx = blockIdx.x * (TB / 16) + (threadIdx.x >> 4);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int n0 = 0; n0 < N; n0 += U3_PTS) {
+    const int cnt = min(U3_PTS, N - n0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < cnt; j += TB) {
+      long pix = choose[(size_t)b * N + n0 + j];
+      pix = pix < 0 ? 0 : (pix >= HW ? HW - 1 : pix);
+      const int py = (int)(pix / OW), px = (int)(pix % OW);
+      int i0, i1;
+      float l0, l1;
+      s_py[j] = (short)py; s_px[j] = (short)px;
+      bil_src(max(py - 1, 0), h, OH, 1, i0, i1, l0, l1); s_rlo[j] = (short)i0;
+      bil_src(min(py + 1, OH - 1), h, OH, 1, i0, i1, l0, l1); s_rhi[j] = (short)i1;
+      bil_src(max(px - 1, 0), wd, OW, 1, i0, i1, l0, l1); s_clo[j] = (short)i0;
+      bil_src(min(px + 1, OW - 1), wd, OW, 1, i0, i1, l0, l1); s_chi[j] = (short)i1;
+    }
+    __syncthreads();
+    if (qx < wd) {
+      for (int j = 0; j < cnt; ++j) {
+        if (qy < s_rlo[j] || qy > s_rhi[j] || qx < s_clo[j] || qx > s_chi[j]) continue;
+        const float *row = dpatch + ((size_t)b * Npad + n0 + j) * 576 + c4 * 4;
+        const int py = s_py[j], px = s_px[j];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int uy = py + dy - 1;
+          if ((unsigned)uy >= (unsigned)OH) continue;
+          int y0, y1;
+          float wy0, wy1;
+          bil_src(uy, h, OH, 1, y0, y1, wy0, wy1);
+          if (y0 != qy && y1 != qy) continue;
+          const float wy = (y0 == qy ? wy0 : 0.f) + (y1 == qy ? wy1 : 0.f);
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int ux = px + dx - 1;
+            if ((unsigned)ux >= (unsigned)OW) continue;
+            int x0, x1;
+            float wx0, wx1;
+            bil_src(ux, wd, OW, 1, x0, x1, wx0, wx1);
+            if (x0 != qx && x1 != qx) continue;
+            const float wx = (x0 == qx ? wx0 : 0.f) + (x1 == qx ? wx1 : 0.f);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(row + (dy * 3 + dx) * 64);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += (wy * wx) * v[e];
+          }
+        }
+      }
+    }
+  }
+  if (qx < wd) *reinterpret_cast<f32x4 *>(dU + (((size_t)b * h + qy) * wd + qx) * 64 + c4 * 4) = acc;
+}
+
+// Conv1d(3, 64, 1) on the cloud (lib/network.py:54): partial sums of dW [64][3], db [64] over a chunk of 256 points;
+// g = the masked gradient of its output, a [B*Npad][64] view.  part[chunk][64][4] = (dW_x, dW_y, dW_z, db)
+__global__ __launch_bounds__(64) void cloud_conv1_bwd_kernel(const float *__restrict__ g, int g_ld, const float *__restrict__ cloud, int B, int N,
+                                                             int Npad, float *__restrict__ part) {
+  const int chunks = (N + 255) / 256;
+  const int b = blockIdx.x / chunks, n0 = (blockIdx.x % chunks) * 256, n1 = min(N, n0 + 256);
+  const int c = threadIdx.x;
+  float ax = 0.f, ay = 0.f, az = 0.f, ab = 0.f;
+  for (int n = n0; n < n1; ++n) {
+    const float gv = g[((size_t)b * Npad + n) * g_ld + c];
+    const float *p = cloud + ((size_t)b * N + n) * 3;
+    ax += gv * p[0]; ay += gv * p[1]; az += gv * p[2]; ab += gv;
+  }
+  float *o = part + ((size_t)blockIdx.x * 64 + c) * 4;
+  o[0] = ax; o[1] = ay; o[2] = az; o[3] = ab;
+}
+__global__ __launch_bounds__(64) void cloud_conv1_bwd_finish_kernel(const float *__restrict__ part, int count, float *__restrict__ dw, float *__restrict__ db) {
+  const int c = threadIdx.x;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < count; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] += part[((size_t)i * 64 + c) * 4 + e];
+  dw[c * 3 + 0] += a[0]; dw[c * 3 + 1] += a[1]; dw[c * 3 + 2] += a[2];
+  db[c] += a[3];
+}
+
+// AvgPool1d(N) adjoint + ReLU mask of conv6's output: g6[r][c] = (n < N && x6[r][c] > 0) ? dap[b][c] / N : 0
+__global__ __launch_bounds__(TB) void mask_bcast_kernel(const float *__restrict__ x6, const float *__restrict__ dap, float *__restrict__ g6, int B, int N,
+                                                        int Npad, int C4) {
+  const float inv = 1.f / (float)N;
+  GRID_STRIDE(i, (long)B * Npad * C4) {
+    const int c = (int)(i % C4);
+    const long r = i / C4;
+    const int b = (int)(r / Npad), n = (int)(r - (long)b * Npad);
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+      const f32x4 x = reinterpret_cast<const f32x4 *>(x6)[i], d = reinterpret_cast<const f32x4 *>(dap)[(long)b * C4 + c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = x[e] > 0.f ? d[e] * inv : 0.f;
+    }
+    reinterpret_cast<f32x4 *>(g6)[i] = o;
+  }
+}
+
+// s[b][c] = sum over the Npad rows of object b of g[.][c]: 32 columns x 8 row lanes per workgroup, rows in ascending order per lane
+__global__ __launch_bounds__(256) void colsum_obj_kernel(const float *__restrict__ g, int g_ld, float *__restrict__ s, int Npad, int C, long rows_total) {
+  __shared__ float s_p[8][32];
+  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + col, b = blockIdx.y;
+  float a = 0.f;
+  if (c < C)
+    for (int r = rl; r < Npad && (long)b * Npad + r < rows_total; r += 8) a += g[((size_t)b * Npad + r) * g_ld + c];
+  s_p[rl][col] = a;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+#pragma unroll
+    for (int l = 1; l < 8; ++l) a += s_p[l][col];
+    s[(size_t)b * C + c] = a;
+  }
+}
+
+// global-feature half of head layer 1 (the 1024 broadcast channels folded into a per-object bias, engine.hip posenet_points):
+//   gbias[b][o] = Wg[o] . ap[b] + bias[o]   =>   dbias[o] += sum_b s[b][o],  dWg[o][j] += sum_b s[b][o] ap[b][j],  dap[b][j] = sum_o Wg[o][j] s[b][o]
+// with s[b][o] = the column sums over object b's points of the masked gradient of head layer 1's output
+__global__ __launch_bounds__(TB) void head1_global_wgrad_kernel(const float *__restrict__ s, const float *__restrict__ ap, float *__restrict__ dWg,
+                                                                float *__restrict__ dbias, int B, int O, int J4) {
+  GRID_STRIDE(i, (long)O * J4) {
+    const int j = (int)(i % J4);
+    const int o = (int)(i / J4);
+    f32x4 acc = reinterpret_cast<const f32x4 *>(dWg)[i];
+    float sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float sv = s[(size_t)b * O + o];
+      const f32x4 a = reinterpret_cast<const f32x4 *>(ap)[(size_t)b * J4 + j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += sv * a[e];
+      sb += sv;
+    }
+    reinterpret_cast<f32x4 *>(dWg)[i] = acc;
+    if (j == 0) dbias[o] += sb;
+  }
+}
+__global__ __launch_bounds__(TB) void head1_global_dgrad_kernel(const float *__restrict__ s, const float *__restrict__ Wg, float *__restrict__ dap, int B,
+                                                                int O, int J) {
+  GRID_STRIDE(i, (long)B * J) {
+    const int j = (int)(i % J);
+    const int b = (int)(i / J);
+    float a = 0.f;
+    for (int o = 0; o < O; ++o) a += Wg[(size_t)o * J + j] * s[(size_t)b * O + o];
+    dap[i] = a;
+  }
+}
+
+// last head layer for the frame's object only (layers.hip head_final): outputs j = 0..3 quaternion, 4..6 translation, 7 confidence
+// (sigmoid).  dz[b][n][j] = upstream gradient of the pre-sigmoid outputs; dh3 = dz . W rows; partial dW rows over chunks of 128 points.
+__global__ __launch_bounds__(TB) void head_final_bwd_kernel(const float *__restrict__ d_r, const float *__restrict__ d_t, const float *__restrict__ d_c,
+                                                            const float *__restrict__ out_c, const float *__restrict__ w_r, const float *__restrict__ w_t,
+                                                            const float *__restrict__ w_c, const int64_t *__restrict__ obj, int num_obj,
+                                                            float *__restrict__ dh3, float *__restrict__ dz, int B, int N, int Npad) {
+  GRID_STRIDE(i, (long)B * Npad * 96) {          // thread = (row, one float4 of the 384 feature columns)
+    const int k4 = (int)(i % 96);
+    const long r = i / 96;
+    const int b = (int)(r / Npad), n = (int)(r - (long)b * Npad);
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+      long ob = obj[b];
+      ob = ob < 0 ? 0 : (ob >= num_obj ? num_obj - 1 : ob);
+      const size_t p = (size_t)b * N + n;
+      const int tower = k4 / 32, k = (k4 % 32) * 4;
+      if (tower == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gz = d_r[p * 4 + j];
+          const f32x4 wv = *reinterpret_cast<const f32x4 *>(w_r + (ob * 4 + j) * 128 + k);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += gz * wv[e];
+          if (k4 == 0) dz[p * 8 + j] = gz;
+        }
+      } else if (tower == 1) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float gz = d_t[p * 3 + j];
+          const f32x4 wv = *reinterpret_cast<const f32x4 *>(w_t + (ob * 3 + j) * 128 + k);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += gz * wv[e];
+          if (k4 == 32) dz[p * 8 + 4 + j] = gz;
+        }
+      } else {
+        const float cv = out_c[p];
+        const float gz = d_c[p] * cv * (1.f - cv);
+        const f32x4 wv = *reinterpret_cast<const f32x4 *>(w_c + ob * 128 + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = gz * wv[e];
+        if (k4 == 64) dz[p * 8 + 7] = gz;
+      }
+    }
+    *reinterpret_cast<f32x4 *>(dh3 + r * 384 + k4 * 4) = o;
+  }
+}
+// part[b][chunk][j][k] = sum over the chunk's points of dz[n][j] * h3[n][tower(j)*128 + k]; block = (chunk, b), thread = (j pair, k)
+__global__ __launch_bounds__(TB) void head_final_wgrad_kernel(const float *__restrict__ dz, const float *__restrict__ h3, float *__restrict__ part,
+                                                              float *__restrict__ zpart, int N, int Npad, int chunks) {
+  const int b = blockIdx.y, ch = blockIdx.x, n0 = ch * 128, n1 = min(N, n0 + 128);
+  const int k = threadIdx.x & 127, jh = threadIdx.x >> 7;       // jh 0: outputs 0..3 (r), 1: outputs 4..7 (t, c)
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int n = n0; n < n1; ++n) {
+    const float *z = dz + ((size_t)b * N + n) * 8 + jh * 4;
+    const float *hrow = h3 + ((size_t)b * Npad + n) * 384;
+    const float hr = hrow[(jh == 0 ? 0 : 128) + k], hc = hrow[256 + k];
+    a[0] += z[0] * hr; a[1] += z[1] * hr; a[2] += z[2] * hr;
+    a[3] += z[3] * (jh == 0 ? hr : hc);
+  }
+  float *o = part + (((size_t)b * chunks + ch) * 8 + jh * 4) * 128 + k;
+  o[0] = a[0]; o[128] = a[1]; o[256] = a[2]; o[384] = a[3];
+  if (k == 0) {                       // the chunk's sums of dz (bias gradient)
+    float zs[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int n = n0; n < n1; ++n) {
+      const float *z = dz + ((size_t)b * N + n) * 8 + jh * 4;
+      zs[0] += z[0]; zs[1] += z[1]; zs[2] += z[2]; zs[3] += z[3];
+    }
+    float *zo = zpart + ((size_t)b * chunks + ch) * 8 + jh * 4;
+    zo[0] = zs[0]; zo[1] = zs[1]; zo[2] = zs[2]; zo[3] = zs[3];
+  }
+}
+// thread = (j, k): frames in ascending order add their chunks (ascending) into the rows of their object; db from dz directly
+__global__ __launch_bounds__(TB) void head_final_wgrad_finish_kernel(const float *__restrict__ part, const float *__restrict__ zpart,
+                                                                     const int64_t *__restrict__ obj, int num_obj, float *__restrict__ dw_r,
+                                                                     float *__restrict__ db_r, float *__restrict__ dw_t, float *__restrict__ db_t,
+                                                                     float *__restrict__ dw_c, float *__restrict__ db_c, int B, int N, int chunks) {
+  const int i = blockIdx.x * TB + threadIdx.x;
+  if (i >= 8 * 128) return;
+  const int j = i >> 7, k = i & 127;
+  for (int b = 0; b < B; ++b) {
+    long ob = obj[b];
+    ob = ob < 0 ? 0 : (ob >= num_obj ? num_obj - 1 : ob);
+    float a = 0.f;
+    for (int ch = 0; ch < chunks; ++ch) a += part[(((size_t)b * chunks + ch) * 8 + j) * 128 + k];
+    float *dst = j < 4 ? dw_r + (ob * 4 + j) * 128 : j < 7 ? dw_t + (ob * 3 + (j - 4)) * 128 : dw_c + ob * 128;
+    dst[k] += a;
+    if (k == 0) {
+      float s = 0.f;
+      for (int ch = 0; ch < chunks; ++ch) s += zpart[((size_t)b * chunks + ch) * 8 + j];
+      float *bd = j < 4 ? db_r + ob * 4 + j : j < 7 ? db_t + ob * 3 + (j - 4) : db_c + ob;
+      *bd += s;
+    }
+  }
+}
+
+// refiner tail (lib/network.py:199-204): out_r [B][4], out_t [B][3] = conv3_r / conv3_t rows of the frame's object on f2 [B][256]
+__global__ __launch_bounds__(64) void refiner_tail_fwd_kernel(const float *__restrict__ f2, const float *__restrict__ w_r, const float *__restrict__ b_r,
+                                                              const float *__restrict__ w_t, const float *__restrict__ b_t, const int64_t *__restrict__ obj,
+                                                              int num_obj, float *__restrict__ out_r, float *__restrict__ out_t, int B) {
+  const int b = blockIdx.x, j = threadIdx.x;
+  if (b >= B || j >= 7) return;
+  long ob = obj[b];
+  ob = ob < 0 ? 0 : (ob >= num_obj ? num_obj - 1 : ob);
+  const float *w = j < 4 ? w_r + (ob * 4 + j) * 128 : w_t + (ob * 3 + (j - 4)) * 128;
+  const float *x = f2 + (size_t)b * 256 + (j < 4 ? 0 : 128);
+  float a = 0.f;
+  for (int k = 0; k < 128; ++k) a += x[k] * w[k];
+  if (j < 4) out_r[b * 4 + j] = a + b_r[ob * 4 + j];
+  else out_t[b * 3 + (j - 4)] = a + b_t[ob * 3 + (j - 4)];
+}
+// one workgroup: frames in ascending order; df2[b][tower*128 + k] = sum_j dz[j] W[j][k]; dW rows += dz[j] f2[k]; db += dz
+__global__ __launch_bounds__(128) void refiner_tail_bwd_kernel(const float *__restrict__ d_r, const float *__restrict__ d_t, const float *__restrict__ f2,
+                                                               const float *__restrict__ w_r, const float *__restrict__ w_t, const int64_t *__restrict__ obj,
+                                                               int num_obj, float *__restrict__ df2, float *__restrict__ dw_r, float *__restrict__ db_r,
+                                                               float *__restrict__ dw_t, float *__restrict__ db_t, int B) {
+  const int k = threadIdx.x;
+  for (int b = 0; b < B; ++b) {
+    long ob = obj[b];
+    ob = ob < 0 ? 0 : (ob >= num_obj ? num_obj - 1 : ob);
+    float ar = 0.f, at = 0.f;
+    const float xr = f2[(size_t)b * 256 + k], xt = f2[(size_t)b * 256 + 128 + k];
+    for (int j = 0; j < 4; ++j) {
+      const float gz = d_r[b * 4 + j];
+      ar += gz * w_r[(ob * 4 + j) * 128 + k];
+      dw_r[(ob * 4 + j) * 128 + k] += gz * xr;
+      if (k == 0) db_r[ob * 4 + j] += gz;
+    }
+    for (int j = 0; j < 3; ++j) {
+      const float gz = d_t[b * 3 + j];
+      at += gz * w_t[(ob * 3 + j) * 128 + k];
+      dw_t[(ob * 3 + j) * 128 + k] += gz * xt;
+      if (k == 0) db_t[ob * 3 + j] += gz;
+    }
+    df2[(size_t)b * 256 + k] = ar;
+    df2[(size_t)b * 256 + 128 + k] = at;
+    __syncthreads();
+  }
+}
+
+// wt[z][c][tap'][n] = w[z][n][tap][c], tap' = the tap mirrored through the kernel centre (what the data gradient convolves with)
+__global__ __launch_bounds__(TB) void flip_kernel(const float *__restrict__ w, float *__restrict__ wt, int O, int T, int I, int KH, int KW, int Z) {
+  const long per = (long)O * T * I;
+  GRID_STRIDE(i, per * Z) {
+    const long z = i / per, l = i - z * per;
+    const int n = (int)(l % O);
+    const long r = l / O;
+    const int t = (int)(r % T);
+    const long c = r / T;
+    const int ky = t / KW, kx = t - ky * KW;
+    const int tf = (KH - 1 - ky) * KW + (KW - 1 - kx);
+    wt[i] = w[z * per + ((size_t)n * T + tf) * I + c];
+  }
+}
+
+// layout conversion between the reference's state-dict tensors and the flat kernel layout
+//   mode 0: OIHW [O][I][T] <-> O(T)Ipad          mode 1: OIHW (T = 9) <-> tap-major [9][O][I]          (dir 0: pack, 1: unpack)
+__global__ __launch_bounds__(TB) void relayout_kernel(const float *__restrict__ src, float *__restrict__ dst, int O, int I, int T, int Ipad, int mode,
+                                                      int dir) {
+  GRID_STRIDE(i, (long)O * T * Ipad) {
+    const int c = (int)(i % Ipad);
+    const long r = i / Ipad;
+    const int t = (int)(r % T);
+    const long o = r / T;
+    const size_t ref = ((size_t)o * I + c) * T + t;
+    const size_t ker = mode == 0 ? (size_t)i : ((size_t)t * O + o) * I + c;
+    if (dir == 0) dst[ker] = c < I ? src[ref] : 0.f;
+    else if (c < I) dst[ref] = src[ker];
+  }
+}
+__global__ __launch_bounds__(TB) void copy2d_kernel(const float *__restrict__ src, long s_ld, float *__restrict__ dst, long d_ld, long rows, long width) {
+  GRID_STRIDE(i, rows * width) {
+    const long r = i / width, c = i - r * width;
+    dst[r * d_ld + c] = src[r * s_ld + c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// trainer handle: parameter spec (reference keys / shapes) and where every tensor lives in the flat buffer
+// ------------------------------------------------------------------------------------------------
+struct PSpec {
+  std::string key;
+  int64_t shape[4] = {1, 1, 1, 1};
+  int ndim = 0;
+  // kernel-layout placement: up to two pieces (head layer 1's weight splits into the per-point and the global-feature block)
+  int mode = 2;             // 0 OIHW->O(T)Ipad, 1 OIHW->tap-major, 2 plain copy, 3 head-1 weight split, 4 rows of a stacked tensor
+  size_t off = 0, off2 = 0; // flat offsets (floats); off2: second piece of mode 3
+  size_t kfloats = 0;       // floats this tensor occupies in the flat buffer
+  int64_t numel() const { int64_t n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i]; return n; }
+};
+
+struct Trainer {
+  int kind = 0, N = 0, K = 0, device = 0;
+  std::vector<PSpec> spec;
+  std::map<std::string, int> index;
+  std::map<std::string, size_t> slot;        // internal name -> flat offset
+  size_t flat = 0;
+  // flipped / transposed weights for the data gradients, rebuilt when the caller's parameter version changes
+  float *wflip = nullptr;
+  long flip_version = -1;
+  const float *flip_src = nullptr;
+  struct Flip { size_t off; int O, T, I, KH, KW, Z; };
+  std::vector<Flip> flips;
+};
+
+size_t take(Trainer &t, const std::string &name, size_t floats) {
+  const size_t o = t.flat;
+  t.slot[name] = o;
+  t.flat += (floats + 63) / 64 * 64;          // 256-byte aligned slots
+  return o;
+}
+
+void add_spec(Trainer &t, const std::string &key, std::initializer_list<int64_t> shp, int mode, size_t off, size_t kfloats, size_t off2 = 0) {
+  PSpec p;
+  p.key = key;
+  p.ndim = (int)shp.size();
+  int i = 0;
+  for (auto v : shp) p.shape[i++] = v;
+  p.mode = mode; p.off = off; p.off2 = off2; p.kfloats = kfloats;
+  t.index[key] = (int)t.spec.size();
+  t.spec.push_back(p);
+}
+
+// as_gemm: the step uses the packed [O][(ky,kx,c)] rows as a plain GEMM operand (up_3 on chosen-pixel patches): its data gradient
+// needs the plain transpose, not the tap-mirrored one
+void add_conv(Trainer &t, const std::string &key, int O, int I, int k, bool tapmajor = false, bool as_gemm = false) {
+  const int Ipad = (I + 3) / 4 * 4, T = k * k;
+  const size_t fl = (size_t)O * T * Ipad;
+  const size_t off = take(t, key, fl);
+  add_spec(t, key, {O, I, k, k}, tapmajor ? 1 : 0, off, fl);
+  if (tapmajor) t.flips.push_back({off, 9 * O, 1, I, 1, 1, 1});        // the low-resolution product is a 1x1 conv with 9*O outputs
+  else if (as_gemm) t.flips.push_back({off, O, 1, T * Ipad, 1, 1, 1});
+  else t.flips.push_back({off, O, T, Ipad, k, k, 1});
+}
+void add_plain(Trainer &t, const std::string &key, std::initializer_list<int64_t> shp) {
+  size_t n = 1;
+  for (auto v : shp) n *= (size_t)v;
+  add_spec(t, key, shp, 2, take(t, key, n), n);
+}
+// Conv1d(k=1) / Linear weight [O][I] used as a GEMM operand (needs its transpose for the data gradient)
+void add_gemm(Trainer &t, const std::string &key, int O, int I, bool conv1d) {
+  const size_t off = take(t, key, (size_t)O * I);
+  if (conv1d) add_spec(t, key, {O, I, 1}, 2, off, (size_t)O * I);
+  else add_spec(t, key, {O, I}, 2, off, (size_t)O * I);
+  t.flips.push_back({off, O, 1, I, 1, 1, 1});
+}
+
+const char *CNN = "cnn.model.module.";
+
+void build_posenet(Trainer &t) {
+  const std::string c = CNN;
+  add_conv(t, c + "feats.conv1.weight", 64, 3, 7);
+  int inpl = 64;
+  const int planes_of[4] = {64, 128, 256, 512};
+  for (int li = 1; li <= 4; ++li) {
+    const int planes = planes_of[li - 1];
+    for (int blk = 0; blk < 2; ++blk) {
+      const int cin = blk == 0 ? inpl : planes;
+      const std::string base = c + "feats.layer" + std::to_string(li) + "." + std::to_string(blk) + ".";
+      add_conv(t, base + "conv1.weight", planes, cin, 3);
+      add_conv(t, base + "conv2.weight", planes, planes, 3);
+      if (blk == 0 && cin != planes) add_conv(t, base + "downsample.0.weight", planes, cin, 1);
+    }
+    inpl = planes;
+  }
+  for (int s = 0; s < 4; ++s) add_conv(t, c + "psp.stages." + std::to_string(s) + ".1.weight", 512, 512, 1);
+  add_conv(t, c + "psp.bottleneck.weight", 1024, 2560, 1);
+  add_plain(t, c + "psp.bottleneck.bias", {1024});
+  const char *ups[3] = {"up_1", "up_2", "up_3"};
+  const int up_in[3] = {1024, 256, 64}, up_out[3] = {256, 64, 64};
+  for (int u = 0; u < 3; ++u) {
+    add_conv(t, c + ups[u] + ".conv.1.weight", up_out[u], up_in[u], 3, u < 2, u == 2);
+    add_plain(t, c + ups[u] + ".conv.1.bias", {up_out[u]});
+    add_plain(t, c + ups[u] + ".conv.2.weight", {1});
+  }
+  add_conv(t, c + "final.0.weight", 32, 64, 1);
+  add_plain(t, c + "final.0.bias", {32});
+  add_plain(t, c + "classifier.0.weight", {256, 256});     // dead weights (lib/pspnet.py:58-62): carried, never touched
+  add_plain(t, c + "classifier.0.bias", {256});
+  add_plain(t, c + "classifier.2.weight", {21, 256});
+  add_plain(t, c + "classifier.2.bias", {21});
+  add_plain(t, "feat.conv1.weight", {64, 3, 1});
+  add_plain(t, "feat.conv1.bias", {64});
+  const char *fn[5] = {"conv2", "e_conv1", "e_conv2", "conv5", "conv6"};
+  const int fi[5] = {64, 32, 64, 256, 512}, fo[5] = {128, 64, 128, 512, 1024};
+  // reference order of the keys: conv1, conv2, e_conv1, e_conv2, conv5, conv6 (weights then biases per layer)
+  for (int i = 0; i < 5; ++i) {
+    add_gemm(t, std::string("feat.") + fn[i] + ".weight", fo[i], fi[i], true);
+    add_plain(t, std::string("feat.") + fn[i] + ".bias", {fo[i]});
+  }
+  // head layer 1: towers stacked r, t, c; per-point block [1920][384], global-feature block [1920][1024], bias [1920]
+  const size_t wpt = take(t, "head1.wpt", (size_t)1920 * 384), wg = take(t, "head1.wg", (size_t)1920 * 1024), b1 = take(t, "head1.bias", 1920);
+  t.flips.push_back({wpt, 1920, 1, 384, 1, 1, 1});
+  const size_t w2 = take(t, "head2.w", (size_t)3 * 256 * 640), b2 = take(t, "head2.bias", 768);
+  t.flips.push_back({w2, 256, 1, 640, 1, 1, 3});
+  const size_t w3 = take(t, "head3.w", (size_t)3 * 128 * 256), b3 = take(t, "head3.bias", 384);
+  t.flips.push_back({w3, 128, 1, 256, 1, 1, 3});
+  const char *hs[3] = {"r", "t", "c"};
+  const int hin[3] = {1408, 640, 256}, hout[3] = {640, 256, 128};
+  for (int l = 0; l < 3; ++l)
+    for (int h = 0; h < 3; ++h) {
+      const std::string nm = "conv" + std::to_string(l + 1) + "_" + hs[h];
+      if (l == 0) {
+        add_spec(t, nm + ".weight", {640, 1408, 1}, 3, wpt + (size_t)h * 640 * 384, (size_t)640 * 1408, wg + (size_t)h * 640 * 1024);
+        add_spec(t, nm + ".bias", {640}, 2, b1 + (size_t)h * 640, 640);
+      } else {
+        const size_t w = l == 1 ? w2 : w3, b = l == 1 ? b2 : b3;
+        add_spec(t, nm + ".weight", {hout[l], hin[l], 1}, 2, w + (size_t)h * hout[l] * hin[l], (size_t)hout[l] * hin[l]);
+        add_spec(t, nm + ".bias", {hout[l]}, 2, b + (size_t)h * hout[l], hout[l]);
+      }
+    }
+  const int per[3] = {4, 3, 1};
+  for (int h = 0; h < 3; ++h) {
+    const std::string nm = std::string("conv4_") + hs[h];
+    add_plain(t, nm + ".weight", {(int64_t)t.K * per[h], 128, 1});
+    add_plain(t, nm + ".bias", {(int64_t)t.K * per[h]});
+  }
+}
+
+void build_refiner(Trainer &t) {
+  add_plain(t, "feat.conv1.weight", {64, 3, 1});
+  add_plain(t, "feat.conv1.bias", {64});
+  const char *fn[5] = {"conv2", "e_conv1", "e_conv2", "conv5", "conv6"};
+  const int fi[5] = {64, 32, 64, 384, 512}, fo[5] = {128, 64, 128, 512, 1024};
+  for (int i = 0; i < 5; ++i) {
+    add_gemm(t, std::string("feat.") + fn[i] + ".weight", fo[i], fi[i], true);
+    add_plain(t, std::string("feat.") + fn[i] + ".bias", {fo[i]});
+  }
+  const int li[2] = {1024, 512}, lo[2] = {512, 128};
+  const char *hs[2] = {"r", "t"};
+  for (int l = 0; l < 2; ++l)
+    for (int h = 0; h < 2; ++h) {
+      const std::string nm = "conv" + std::to_string(l + 1) + "_" + hs[h];
+      add_gemm(t, nm + ".weight", lo[l], li[l], false);
+      add_plain(t, nm + ".bias", {lo[l]});
+    }
+  const int per[2] = {4, 3};
+  for (int h = 0; h < 2; ++h) {
+    const std::string nm = std::string("conv3_") + hs[h];
+    add_plain(t, nm + ".weight", {(int64_t)t.K * per[h], 128});
+    add_plain(t, nm + ".bias", {(int64_t)t.K * per[h]});
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// step plumbing: workspace arena, activation records, the backward tape
+// ------------------------------------------------------------------------------------------------
+struct View { float *d = nullptr; int ld = 0; };           // [rows][C] view: element (r, c) at d[r * ld + c] (d already offset to its channel)
+
+struct Act {
+  View v, g;                    // values; gradient (allocated / aliased during the backward pass)
+  int B = 1, H = 1, W = 1, C = 0;
+  bool gset = false;
+  long rows() const { return (long)B * H * W; }
+};
+
+struct Step {
+  Trainer *t;
+  hipStream_t st;
+  bool dry;
+  char *base;
+  size_t off = 0, cap = 0, peak = 0;
+  int err = DF_OK;
+  const float *P = nullptr;      // flat parameters
+  float *G = nullptr;            // flat gradients (accumulated)
+  float *splitk = nullptr;
+  size_t splitk_bytes = 0;
+  std::deque<Act> acts;
+  std::vector<std::function<void()>> tape;
+
+  void *bytes(size_t b) {
+    b = (b + 255) & ~size_t(255);
+    // the sizing pass hands out (never dereferenced) non-null addresses too, so that every "is there a buffer yet" decision of the
+    // backward pass comes out as in the real run: both passes allocate the same sequence by construction
+    void *p = (dry ? reinterpret_cast<char *>(4096) : base) + off;
+    off += b;
+    if (off > peak) peak = off;
+    if (!dry && off > cap && err == DF_OK) err = set_error(DF_ERR_WORKSPACE, "train step: workspace too small (need > %zu bytes, have %zu)", off, cap);
+    return p;
+  }
+  float *f(size_t n) { return static_cast<float *>(bytes(n * sizeof(float))); }
+  bool live() const { return !dry && err == DF_OK; }
+  // DF_TRAIN_DEBUG=1: synchronise after every phase and name it on stderr (localises a faulting launch)
+  void dbg(const char *what, const std::string &extra = std::string()) {
+    static const bool on = getenv("DF_TRAIN_DEBUG") != nullptr;
+    if (!on || dry) return;
+    const hipError_t e = hipStreamSynchronize(st);
+    fprintf(stderr, "[df-train] %s %s: %s\n", what, extra.c_str(), e == hipSuccess ? "ok" : hipGetErrorString(e));
+    fflush(stderr);
+  }
+  void fail(int rc) { if (rc != DF_OK && err == DF_OK) err = rc; }
+  size_t slot(const std::string &name) {
+    auto it = t->slot.find(name);
+    if (it == t->slot.end()) {
+      if (err == DF_OK) err = set_error(DF_ERR_STATE, "trainer: no parameter slot named '%s'", name.c_str());
+      return 0;
+    }
+    return it->second;
+  }
+  const float *p(const std::string &name, size_t extra = 0) { const size_t o = slot(name); return dry ? nullptr : P + o + extra; }
+  float *gr(const std::string &name, size_t extra = 0) { const size_t o = slot(name); return dry ? nullptr : G + o + extra; }
+  const float *pf(const std::string &name, size_t extra = 0) { const size_t o = slot(name); return dry ? nullptr : t->wflip + o + extra; }
+  Act *act(int B, int H, int W, int C, float *d = nullptr, int ld = 0) {
+    acts.emplace_back();
+    Act *a = &acts.back();
+    a->B = B; a->H = H; a->W = W; a->C = C;
+    a->v.d = d ? d : f((size_t)B * H * W * C);
+    a->v.ld = d ? ld : C;
+    return a;
+  }
+  // gradient storage of `a` for a producer that is about to write (returns true when it has to ACCUMULATE)
+  bool grad_of(Act *a) {
+    if (!a->g.d) { a->g.d = f((size_t)a->rows() * a->C); a->g.ld = a->C; }
+    const bool acc = a->gset;
+    a->gset = true;
+    return acc;
+  }
+};
+
+ConvParams base_params(const Act *x, int cin, const float *w, const float *bias, Act *y, int k, int stride, int pad, int dil, int act) {
+  ConvParams p;
+  p.in = x->v.d; p.wgt = w; p.bias = bias; p.out = y->v.d;
+  p.B = x->B; p.H = x->H; p.W = x->W; p.Cin = cin; p.in_ld = x->v.ld;
+  p.OH = y->H; p.OW = y->W; p.Cout = y->C; p.out_ld = y->v.ld;
+  p.KH = p.KW = k; p.stride = stride; p.pad = pad; p.dil = dil; p.act = act;
+  return p;
+}
+
+void launch_act_bwd(Step &s, Act *y, int act, const float *slope, float *dslope) {
+  const long rows = y->rows();
+  const int C4 = y->C / 4;
+  const unsigned blocks = act == 2 ? nblk(rows * C4, 1024) : nblk(rows * C4);
+  float *part = act == 2 ? s.f(blocks) : nullptr;
+  if (!s.live()) return;
+  hipLaunchKernelGGL(act_bwd2d_kernel, dim3(blocks), dim3(TB), 0, s.st, y->g.d, y->g.ld, y->v.d, y->v.ld, rows, C4, act, slope, part);
+  if (act == 2) hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(TB), 0, s.st, part, (int)blocks, 1L, dslope, 1);
+}
+
+// weight / bias gradient of forward conv `f` with upstream gradient view gy, accumulated into dw / db
+void wgrad(Step &s, ConvParams f, View gy, float *dw, float *db) {
+  f.out = gy.d; f.out_ld = gy.ld; f.out_coff = 0;
+  f.bias = nullptr; f.res = nullptr; f.act = ACT_NONE; f.zcount = 1;
+  f.rows_per_group = f.rows_valid = f.bias_group_ld = 0;
+  const size_t mark = s.off;
+  const size_t need = wgrad_workspace_bytes(f);
+  void *ws = s.bytes(need);
+  if (s.live()) s.fail(launch_wgrad(f, dw, db, ws, need, s.st, 1));
+  s.dbg("wgrad");
+  s.off = mark;
+}
+
+// data gradient of forward conv `f` (cached flipped weights): dx (+)= conv^T(gy)
+void dgrad(Step &s, const ConvParams &f, View gy, View dx, const float *wflip, bool accumulate) {
+  ConvParams q;
+  q.in = gy.d; q.B = f.B; q.H = f.OH; q.W = f.OW; q.Cin = f.Cout; q.in_ld = gy.ld;
+  q.wgt = wflip;
+  q.out = dx.d; q.OH = f.H; q.OW = f.W; q.Cout = f.Cin; q.out_ld = dx.ld;
+  q.KH = f.KH; q.KW = f.KW; q.stride = 1; q.up = f.stride; q.dil = f.dil; q.pad = f.dil * (f.KH - 1) - f.pad;
+  if (accumulate) { q.res = dx.d; q.res_ld = dx.ld; }
+  if (f.zcount > 1) {      // (a split-K launch walks blockIdx.z too: the z strides must stay zero for everything else)
+    q.zcount = f.zcount; q.z_in_coff = f.z_out_coff; q.z_out_coff = f.z_in_coff; q.z_wgt = (long)f.Cin * f.Cout * f.KH * f.KW;
+  }
+  q.splitk_ws = s.splitk; q.splitk_ws_bytes = s.splitk_bytes;
+  if (s.live()) s.fail(launch_conv(q, s.st));
+  s.dbg("dgrad");
+}
+
+struct ConvW {
+  std::string name;            // slot of the weight (its flipped copy and gradient share the offset)
+  size_t woff = 0;             // extra offset inside the slot
+  std::string bias;            // slot of the bias ("" = none)
+  size_t boff = 0;
+  std::string slope;           // PReLU slope slot
+};
+
+// y = act(conv(x) + bias + res); registers its backward.  x_cin / x view: the first x_cin channels of x's view are consumed.
+Act *conv(Step &s, Act *x, int cin, const ConvW &cw, int cout, int k, int stride, int pad, int dil, int act, Act *res = nullptr, Act *into = nullptr,
+          bool need_dx = true) {
+  Act *y = into ? into : s.act(x->B, conv_out(x->H, k, stride, pad, dil), conv_out(x->W, k, stride, pad, dil), cout);
+  ConvParams p = base_params(x, cin, s.p(cw.name, cw.woff), cw.bias.empty() ? nullptr : s.p(cw.bias, cw.boff), y, k, stride, pad, dil, act);
+  if (res) { p.res = res->v.d; p.res_ld = res->v.ld; }
+  if (act == ACT_PRELU) p.prelu = s.p(cw.slope);
+  p.splitk_ws = s.splitk; p.splitk_ws_bytes = s.splitk_bytes;
+  if (s.live()) s.fail(launch_conv(p, s.st));
+  s.dbg("conv fwd", cw.name);
+  Step *sp = &s;
+  s.tape.push_back([=]() {
+    Step &s = *sp;
+    s.dbg("conv bwd begin", cw.name);
+    if (act != ACT_NONE) launch_act_bwd(s, y, act, act == ACT_PRELU ? s.p(cw.slope) : nullptr, act == ACT_PRELU ? s.gr(cw.slope) : nullptr);
+    wgrad(s, p, y->g, s.gr(cw.name, cw.woff), cw.bias.empty() ? nullptr : s.gr(cw.bias, cw.boff));
+    if (need_dx) {
+      const bool acc = s.grad_of(x);
+      dgrad(s, p, y->g, x->g, s.pf(cw.name, cw.woff), acc);
+    }
+    if (res) {
+      if (!res->gset) { res->g = y->g; res->gset = true; }          // the residual's gradient IS this (masked) gradient: alias, no copy
+      else if (s.live()) hipLaunchKernelGGL(add2d_kernel, dim3(nblk(y->rows() * (y->C / 4))), dim3(TB), 0, s.st, res->g.d, res->g.ld, y->g.d, y->g.ld,
+                                            y->rows(), y->C / 4);
+    }
+  });
+  return y;
+}
+
+// channel view [c0, c0 + C) of a wider activation record (shares storage; its gradient view is resolved lazily by the caller)
+Act *slice(Step &s, Act *a, int c0, int C) {
+  s.acts.emplace_back();
+  Act *v = &s.acts.back();
+  *v = *a;
+  v->v.d = a->v.d + c0;
+  v->C = C;
+  v->g = View{};
+  v->gset = false;
+  return v;
+}
+
+int check_flips(Trainer &t, const float *P, long version, hipStream_t st) {
+  if (!t.wflip) return set_error(DF_ERR_STATE, "trainer: created without a device (no arena for the data gradients' weight copies)");
+  if (t.flip_version == version && t.flip_src == P && version >= 0) return DF_OK;
+  for (const Trainer::Flip &f : t.flips)
+    hipLaunchKernelGGL(flip_kernel, dim3(nblk((long)f.O * f.T * f.I * f.Z, 1024)), dim3(TB), 0, st, P + f.off, t.wflip + f.off, f.O, f.T, f.I, f.KH, f.KW, f.Z);
+  t.flip_version = version;
+  t.flip_src = P;
+  return check_launch("trainer: weight flips");
+}
+
+// ------------------------------------------------------------------------------------------------
+// PoseNet step
+// ------------------------------------------------------------------------------------------------
+struct PoseNetIO {
+  int B, H, W, M;
+  const float *img, *cloud, *target, *model_points;
+  const int64_t *choose, *obj;
+  const int *symmetric;     // host [B]
+  float w;
+  int dropout;
+  unsigned seed;
+  float *loss, *dis, *new_points, *new_target;        // [B], [B], [B][N][3], [B][M][3]
+  float *out_r, *out_t, *out_c, *emb;                 // optional copies of the predictions ([B][N][4] ...); emb [B][32][N]
+};
+
+Act *basic_block(Step &s, Act *x, int cin, const std::string &base, int planes, int stride, int dil, bool has_ds, Act *out_into = nullptr) {
+  Act *t = conv(s, x, cin, ConvW{base + "conv1.weight"}, planes, 3, stride, dil, dil, ACT_RELU);
+  Act *res = x;
+  if (has_ds) res = conv(s, x, cin, ConvW{base + "downsample.0.weight"}, planes, 1, stride, 0, 1, ACT_NONE);
+  return conv(s, t, planes, ConvW{base + "conv2.weight"}, planes, 3, 1, dil, dil, ACT_RELU, res, out_into);
+}
+
+// Dropout2d (lib/pspnet.py:46,52): one keep / drop decision per (frame, channel); out of place -- the PReLU gradient upstream needs
+// the un-scaled activation
+Act *dropout2d(Step &s, Act *a, float p, unsigned seed) {
+  float *scale = s.f((size_t)a->B * a->C);
+  Act *o = s.act(a->B, a->H, a->W, a->C);
+  if (s.live()) {
+    s.fail(df_dropout2d_mask(scale, (int64_t)a->B * a->C, seed, p, s.st));
+    s.fail(df_channel_scale(a->v.d, scale, o->v.d, a->B, (int64_t)a->H * a->W, a->C, s.st));
+  }
+  Step *sp = &s;
+  s.tape.push_back([=]() {
+    Step &s = *sp;
+    s.grad_of(a);
+    if (s.live()) s.fail(df_channel_scale(o->g.d, scale, a->g.d, a->B, (int64_t)a->H * a->W, a->C, s.st));
+  });
+  return o;
+}
+
+// PSPUpsample through the low-resolution per-tap products (layers.hip upconv_gather): x [B][h][w][Cin] -> [B][2h][2w][Cout]
+Act *upconv(Step &s, Act *x, const std::string &base, int cin, int cout) {
+  const int B = x->B, h = x->H, w = x->W;
+  Act *y = s.act(B, h, w, 9 * cout);
+  const ConvW cw{base + "conv.1.weight"};
+  ConvParams p = base_params(x, cin, s.p(cw.name), nullptr, y, 1, 1, 0, 1, ACT_NONE);
+  p.splitk_ws = s.splitk; p.splitk_ws_bytes = s.splitk_bytes;
+  if (s.live()) s.fail(launch_conv(p, s.st));
+  Act *o = s.act(B, 2 * h, 2 * w, cout);
+  if (s.live()) launch_upconv_gather(y->v.d, s.p(base + "conv.1.bias"), s.p(base + "conv.2.weight"), o->v.d, B, h, w, cout, s.st);
+  Step *sp = &s;
+  s.tape.push_back([=]() {
+    Step &s = *sp;
+    launch_act_bwd(s, o, ACT_PRELU, s.p(base + "conv.2.weight"), s.gr(base + "conv.2.weight"));
+    {   // bias gradient: column sums of the pre-activation gradient over all pixels
+      const long rows = o->rows();
+      const int nb = (int)((rows + 255) / 256);
+      float *part = s.f((size_t)nb * cout);
+      if (s.live()) {
+        hipLaunchKernelGGL(colsum_obj_kernel, dim3((cout + 31) / 32, nb), dim3(256), 0, s.st, o->g.d, o->g.ld, part, 256, cout, rows);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(nblk(cout)), dim3(TB), 0, s.st, part, nb, (long)cout, s.gr(base + "conv.1.bias"), 1);
+      }
+    }
+    s.grad_of(y);
+    if (s.live()) hipLaunchKernelGGL(upconv_gather_bwd_kernel, dim3(nblk((long)B * h * w * 9 * (cout / 4))), dim3(TB), 0, s.st, o->g.d, y->g.d, B, h, w, cout);
+    wgrad(s, p, y->g, s.gr(cw.name), nullptr);
+    const bool acc = s.grad_of(x);
+    dgrad(s, p, y->g, x->g, s.pf(cw.name), acc);
+  });
+  return o;
+}
+
+void posenet_step(Step &s, const PoseNetIO &io) {
+  Trainer &t = *s.t;
+  const std::string C = CNN;
+  const int B = io.B, N = t.N, Npad = round_up(N, 128), rows = B * Npad;
+  s.splitk_bytes = (size_t)32 << 20;
+  s.splitk = static_cast<float *>(s.bytes(s.splitk_bytes));
+  Step *sp = &s;
+
+  // ---- colour branch (lib/extractors.py:114-124, lib/pspnet.py:64-77) ----
+  Act *img4 = s.act(B, io.H, io.W, 4);
+  if (s.live()) launch_nchw3_to_nhwc4(io.img, img4->v.d, B, io.H, io.W, s.st);
+  Act *stem = conv(s, img4, 4, ConvW{C + "feats.conv1.weight"}, 64, 7, 2, 3, 1, ACT_RELU, nullptr, nullptr, false);
+  Act *x = s.act(B, conv_out(stem->H, 3, 2, 1, 1), conv_out(stem->W, 3, 2, 1, 1), 64);
+  if (s.live()) launch_maxpool3s2(stem->v.d, x->v.d, B, stem->H, stem->W, 64, x->H, x->W, s.st);
+  s.tape.push_back([=]() {
+    Step &s = *sp;
+    s.grad_of(stem);
+    if (s.live()) s.fail(df_maxpool3s2_bwd(stem->v.d, x->g.d, stem->g.d, B, stem->H, stem->W, 64, x->H, x->W, s.st));
+  });
+  int cin = 64;
+  const int planes_of[4] = {64, 128, 256, 512}, stride_of[4] = {1, 2, 1, 1}, dil_of[4] = {1, 1, 2, 4};
+  Act *cat = nullptr;      // [B][h][w][2560]: the four pyramid priors then layer4's output (lib/pspnet.py:23)
+  for (int li = 1; li <= 4; ++li) {
+    const int planes = planes_of[li - 1];
+    const std::string base = C + "feats.layer" + std::to_string(li) + ".";
+    x = basic_block(s, x, cin, base + "0.", planes, stride_of[li - 1], 1, cin != planes || stride_of[li - 1] != 1);
+    Act *into = nullptr;
+    if (li == 4) {          // the last block writes straight into its slot of the PSP concatenation
+      cat = s.act(B, x->H, x->W, 2560);
+      into = slice(s, cat, 2048, 512);
+    }
+    x = basic_block(s, x, planes, base + "1.", planes, 1, dil_of[li - 1], false, into);
+    cin = planes;
+  }
+  const int h = x->H, w = x->W;
+  // PSP module (lib/pspnet.py:20-24): pool -> 1x1 conv -> bilinear (align_corners=False) into the concat slots
+  Act *feat = x;           // == cat[:, 2048:2560]
+  for (int i = 0; i < 4; ++i) {
+    const int sz = i == 0 ? 1 : i == 1 ? 2 : i == 2 ? 3 : 6;
+    Act *pooled = s.act(B, sz, sz, 512);
+    if (s.live()) hipLaunchKernelGGL(pool_fwd_kernel, dim3(nblk((long)B * sz * sz * 128)), dim3(TB), 0, s.st, feat->v.d, feat->v.ld, pooled->v.d, B, h, w, 128, sz);
+    s.tape.push_back([=]() {
+      Step &s = *sp;
+      const bool acc = s.grad_of(feat);
+      if (s.live())
+        hipLaunchKernelGGL(pool_bwd_kernel, dim3(nblk((long)B * h * w * 128)), dim3(TB), 0, s.st, pooled->g.d, feat->g.d, feat->g.ld, B, h, w, 128, sz, acc ? 1 : 0);
+    });
+    Act *z = conv(s, pooled, 512, ConvW{C + "psp.stages." + std::to_string(i) + ".1.weight"}, 512, 1, 1, 0, 1, ACT_NONE);
+    Act *prior = slice(s, cat, 512 * i, 512);
+    if (s.live()) hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(nblk((long)B * h * w * 128)), dim3(TB), 0, s.st, z->v.d, prior->v.d, prior->v.ld, B, sz, sz, 128, h, w, 0);
+    s.tape.push_back([=]() {
+      Step &s = *sp;
+      s.grad_of(z);
+      if (s.live())
+        hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(nblk((long)B * sz * sz * 128)), dim3(TB), 0, s.st, cat->g.d + 512 * i, cat->g.ld, z->g.d, B, sz, sz, 128, h, w, 0);
+    });
+  }
+  // the concat's gradient buffer is one allocation; layer4's output gradient is its last 512 channels
+  s.tape.push_back([=]() {
+    Step &s = *sp;
+    feat->g.d = cat->g.d + 2048;
+    feat->g.ld = 2560;
+    feat->gset = true;
+  });
+  Act *psp = conv(s, cat, 2560, ConvW{C + "psp.bottleneck.weight", 0, C + "psp.bottleneck.bias"}, 1024, 1, 1, 0, 1, ACT_RELU);
+  if (io.dropout) psp = dropout2d(s, psp, 0.3f, io.seed * 4 + 1);
+  Act *u1 = upconv(s, psp, C + "up_1.", 1024, 256);
+  if (io.dropout) u1 = dropout2d(s, u1, 0.15f, io.seed * 4 + 2);
+  Act *u2 = upconv(s, u1, C + "up_2.", 256, 64);
+  if (io.dropout) u2 = dropout2d(s, u2, 0.15f, io.seed * 4 + 3);
+  // up_3 + final 1x1 + LogSoftmax at the chosen pixels only (lib/network.py:98-102 reads nothing else)
+  Act *patch = s.act(rows, 1, 1, 576);
+  if (s.live()) launch_up3_patches(u2->v.d, io.choose, patch->v.d, B, u2->H, u2->W, N, Npad, s.st);
+  s.tape.push_back([=]() {
+    Step &s = *sp;
+    s.grad_of(u2);
+    if (s.live())
+      hipLaunchKernelGGL(up3_patch_bwd_kernel, dim3((u2->W + TB / 16 - 1) / (TB / 16), u2->H, B), dim3(TB), 0, s.st, patch->g.d, io.choose, u2->g.d, u2->H, u2->W,
+                         N, Npad);
+  });
+  Act *z3 = conv(s, patch, 576, ConvW{C + "up_3.conv.1.weight", 0, C + "up_3.conv.1.bias", 0, C + "up_3.conv.2.weight"}, 64, 1, 1, 0, 1, ACT_PRELU);
+  Act *emb_pm = s.act(rows, 1, 1, 32);
+  float *emb = io.emb ? io.emb : s.f((size_t)B * 32 * N);
+  if (s.live()) {
+    hipMemsetAsync(emb_pm->v.d, 0, (size_t)rows * 32 * sizeof(float), s.st);      // rows n >= N feed e_conv1: keep them finite
+    launch_final_logsoftmax(z3->v.d, s.p(C + "final.0.weight"), s.p(C + "final.0.bias"), emb, emb_pm->v.d, B, N, Npad, s.st);
+  }
+  s.tape.push_back([=]() {
+    Step &s = *sp;
+    // LogSoftmax adjoint on the log-probabilities, then the 1x1 conv 64 -> 32 as a GEMM over the chosen pixels' rows
+    float *dlog = s.f((size_t)rows * 32);
+    if (s.live()) s.fail(df_logsoftmax(emb_pm->g.d, emb_pm->v.d, dlog, rows, 32, 1, s.st));
+    Act lg;
+    lg.B = rows; lg.C = 32; lg.v.d = nullptr; lg.v.ld = 32;
+    ConvParams f = base_params(z3, 64, s.p(C + "final.0.weight"), nullptr, &lg, 1, 1, 0, 1, ACT_NONE);
+    wgrad(s, f, View{dlog, 32}, s.gr(C + "final.0.weight"), s.gr(C + "final.0.bias"));
+    s.grad_of(z3);
+    dgrad(s, f, View{dlog, 32}, z3->g, s.pf(C + "final.0.weight"), false);
+  });
+
+  // ---- PoseNetFeat (lib/network.py:53-68) on point rows padded to Npad per frame: pf = [x1 64 | e1 64 | x2 128 | e2 128] ----
+  Act *pf = s.act(rows, 1, 1, 384);
+  Act *x1 = slice(s, pf, 0, 64), *e1 = slice(s, pf, 64, 64), *x2 = slice(s, pf, 128, 128), *e2 = slice(s, pf, 256, 128);
+  if (s.live()) {
+    hipMemsetAsync(pf->v.d, 0, (size_t)rows * 384 * sizeof(float), s.st);
+    launch_cloud_conv1(io.cloud, nullptr, s.p("feat.conv1.weight"), s.p("feat.conv1.bias"), pf->v.d, 384, B, N, Npad, s.st);
+  }
+  // every slice's gradient lives in ONE [rows][384] buffer, written first by head layer 1's data gradient
+  auto pf_grad_views = [=]() {
+    Step &s = *sp;
+    Act *sl[4] = {x1, e1, x2, e2};
+    const int c0[4] = {0, 64, 128, 256};
+    for (int i = 0; i < 4; ++i) { sl[i]->g.d = pf->g.d + c0[i]; sl[i]->g.ld = 384; sl[i]->gset = true; }
+  };
+  s.tape.push_back([=]() {          // conv1's parameters (runs last of the point branch: x1's gradient is complete by then)
+    Step &s = *sp;
+    Act m = *x1;
+    launch_act_bwd(s, &m, ACT_RELU, nullptr, nullptr);
+    const int chunks = (N + 255) / 256;
+    float *part = s.f((size_t)B * chunks * 64 * 4);
+    if (s.live()) {
+      hipLaunchKernelGGL(cloud_conv1_bwd_kernel, dim3(B * chunks), dim3(64), 0, s.st, x1->g.d, 384, io.cloud, B, N, Npad, part);
+      hipLaunchKernelGGL(cloud_conv1_bwd_finish_kernel, dim3(1), dim3(64), 0, s.st, part, B * chunks, s.gr("feat.conv1.weight"), s.gr("feat.conv1.bias"));
+    }
+  });
+  conv(s, emb_pm, 32, ConvW{"feat.e_conv1.weight", 0, "feat.e_conv1.bias"}, 64, 1, 1, 0, 1, ACT_RELU, nullptr, e1);
+  conv(s, x1, 64, ConvW{"feat.conv2.weight", 0, "feat.conv2.bias"}, 128, 1, 1, 0, 1, ACT_RELU, nullptr, x2);
+  conv(s, e1, 64, ConvW{"feat.e_conv2.weight", 0, "feat.e_conv2.bias"}, 128, 1, 1, 0, 1, ACT_RELU, nullptr, e2);
+  Act *pf2 = slice(s, pf, 128, 256);
+  s.tape.push_back([=]() {          // (runs after conv5's backward) nothing to do: pf2's gradient view was set by pf_grad_views
+  });
+  Act *x5 = conv(s, pf2, 256, ConvW{"feat.conv5.weight", 0, "feat.conv5.bias"}, 512, 1, 1, 0, 1, ACT_RELU);
+  // conv6 + ReLU; its mean over the points (AvgPool1d) from the GEMM's fused column sums
+  Act *x6 = s.act(rows, 1, 1, 1024);
+  ConvParams p6 = base_params(x5, 512, s.p("feat.conv6.weight"), s.p("feat.conv6.bias"), x6, 1, 1, 0, 1, ACT_RELU);
+  p6.rows_per_group = Npad; p6.rows_valid = N;
+  int prow;
+  {
+    ConvParams q6 = p6;
+    q6.out = nullptr;            // (the partial-row count is that of the column-sum launch's tile, chosen when out is null or colsum set)
+    prow = conv_colsum_rows(q6);
+  }
+  float *partial = s.f((size_t)prow * 1024);
+  p6.colsum = partial;
+  if (s.live()) s.fail(launch_conv(p6, s.st));
+  float *apx = s.f((size_t)B * 1024), *dap = s.f((size_t)B * 1024);
+  if (s.live()) launch_colsum_finish(partial, prow / B, apx, B, 1024, N, s.st);
+  s.tape.push_back([=]() {
+    Step &s = *sp;
+    s.grad_of(x6);
+    if (s.live()) hipLaunchKernelGGL(mask_bcast_kernel, dim3(nblk((long)rows * 256)), dim3(TB), 0, s.st, x6->v.d, dap, x6->g.d, B, N, Npad, 256);
+    ConvParams f = p6;
+    f.colsum = nullptr;
+    wgrad(s, f, x6->g, s.gr("feat.conv6.weight"), s.gr("feat.conv6.bias"));
+    const bool acc = s.grad_of(x5);
+    dgrad(s, f, x6->g, x5->g, s.pf("feat.conv6.weight"), acc);
+  });
+
+  // ---- heads (lib/network.py:107-131): layer 1 with the global feature folded into a per-frame bias, towers stacked r, t, c ----
+  float *gbias = s.f((size_t)B * 1920), *s1 = s.f((size_t)B * 1920);
+  if (s.live()) launch_fc_rows(apx, 1024, 0, s.p("head1.wg"), s.p("head1.bias"), gbias, 1920, B, 1024, 1920, 1, 0, s.st);
+  Act *h1 = s.act(rows, 1, 1, 1920);
+  ConvParams p1 = base_params(pf, 384, s.p("head1.wpt"), gbias, h1, 1, 1, 0, 1, ACT_RELU);
+  p1.rows_per_group = Npad; p1.rows_valid = N; p1.bias_group_ld = 1920;
+  if (s.live()) s.fail(launch_conv(p1, s.st));
+  s.tape.push_back([=]() {
+    Step &s = *sp;
+    launch_act_bwd(s, h1, ACT_RELU, nullptr, nullptr);
+    wgrad(s, p1, h1->g, s.gr("head1.wpt"), nullptr);
+    s.grad_of(pf);
+    dgrad(s, p1, h1->g, pf->g, s.pf("head1.wpt"), false);
+    pf_grad_views();
+    pf2->g.d = pf->g.d + 128; pf2->g.ld = 384; pf2->gset = true;
+    if (s.live()) {
+      hipLaunchKernelGGL(colsum_obj_kernel, dim3(1920 / 32, B), dim3(256), 0, s.st, h1->g.d, 1920, s1, Npad, 1920, (long)rows);
+      hipLaunchKernelGGL(head1_global_wgrad_kernel, dim3(nblk((long)1920 * 256)), dim3(TB), 0, s.st, s1, apx, s.gr("head1.wg"), s.gr("head1.bias"), B, 1920, 256);
+      hipLaunchKernelGGL(head1_global_dgrad_kernel, dim3(nblk((long)B * 1024)), dim3(TB), 0, s.st, s1, s.p("head1.wg"), dap, B, 1920, 1024);
+    }
+  });
+  Act *h2 = s.act(rows, 1, 1, 768), *h3 = s.act(rows, 1, 1, 384);
+  auto towers = [&](Act *in, int cin_t, Act *out, int cout_t, const std::string &wname, const std::string &bname) {
+    ConvParams p = base_params(in, cin_t, s.p(wname), s.p(bname), out, 1, 1, 0, 1, ACT_RELU);
+    p.Cout = cout_t;
+    p.zcount = 3; p.z_in_coff = cin_t; p.z_wgt = (long)cout_t * cin_t; p.z_bias = cout_t; p.z_out_coff = cout_t;
+    if (s.live()) s.fail(launch_conv(p, s.st));
+    s.tape.push_back([=]() {
+      Step &s = *sp;
+      launch_act_bwd(s, out, ACT_RELU, nullptr, nullptr);
+      for (int z = 0; z < 3; ++z) {
+        ConvParams f = p;
+        f.in = p.in + (size_t)z * cin_t;
+        f.zcount = 1;
+        wgrad(s, f, View{out->g.d + (size_t)z * cout_t, out->g.ld}, s.gr(wname, (size_t)z * cout_t * cin_t), s.gr(bname, (size_t)z * cout_t));
+      }
+      s.grad_of(in);
+      dgrad(s, p, out->g, in->g, s.pf(wname), false);
+    });
+  };
+  towers(h1, 640, h2, 256, "head2.w", "head2.bias");
+  towers(h2, 256, h3, 128, "head3.w", "head3.bias");
+  float *out_r = io.out_r ? io.out_r : s.f((size_t)B * N * 4), *out_t = io.out_t ? io.out_t : s.f((size_t)B * N * 3);
+  float *out_c = io.out_c ? io.out_c : s.f((size_t)B * N);
+  if (s.live())
+    launch_head_final(h3->v.d, s.p("conv4_r.weight"), s.p("conv4_r.bias"), s.p("conv4_t.weight"), s.p("conv4_t.bias"), s.p("conv4_c.weight"),
+                      s.p("conv4_c.bias"), io.obj, t.K, out_r, out_t, out_c, B, N, Npad, s.st);
+  // ---- loss (lib/loss.py:13-70), one frame at a time like the reference, and its gradient w.r.t. the predictions ----
+  float *d_r = s.f((size_t)B * N * 4), *d_t = s.f((size_t)B * N * 3), *d_c = s.f((size_t)B * N);
+  float *dis_n = s.f((size_t)B * N);
+  int *sel = reinterpret_cast<int *>(s.bytes((size_t)B * N * io.M * sizeof(int)));
+  float *np = io.new_points ? io.new_points : s.f((size_t)B * N * 3), *nt = io.new_target ? io.new_target : s.f((size_t)B * io.M * 3);
+  for (int b = 0; b < B && s.live(); ++b) {
+    const int sym = io.symmetric ? io.symmetric[b] : 0;
+    int *sb = sel + (size_t)b * N * io.M;
+    s.fail(df_loss_forward(out_r + (size_t)b * N * 4, out_t + (size_t)b * N * 3, out_c + (size_t)b * N, io.target + (size_t)b * io.M * 3,
+                           io.model_points + (size_t)b * io.M * 3, io.cloud + (size_t)b * N * 3, N, io.M, io.w, sym, io.loss + b, io.dis + b,
+                           np + (size_t)b * N * 3, nt + (size_t)b * io.M * 3, dis_n + (size_t)b * N, sym ? sb : nullptr, s.st));
+    s.fail(df_loss_backward(out_r + (size_t)b * N * 4, out_t + (size_t)b * N * 3, out_c + (size_t)b * N, io.target + (size_t)b * io.M * 3,
+                            io.model_points + (size_t)b * io.M * 3, io.cloud + (size_t)b * N * 3, sym ? sb : nullptr, dis_n + (size_t)b * N, N, io.M,
+                            io.w, 1.f, d_r + (size_t)b * N * 4, d_t + (size_t)b * N * 3, d_c + (size_t)b * N, s.st));
+  }
+  s.dbg("forward + loss");
+  // ---- backward: the last head layer by hand, then the tape in reverse ----
+  {
+    s.grad_of(h3);
+    float *dz = s.f((size_t)B * N * 8);
+    const int chunks = (N + 127) / 128;
+    float *part = s.f((size_t)B * chunks * 8 * 128), *zpart = s.f((size_t)B * chunks * 8);
+    if (s.live()) {
+      hipLaunchKernelGGL(head_final_bwd_kernel, dim3(nblk((long)rows * 96)), dim3(TB), 0, s.st, d_r, d_t, d_c, out_c, s.p("conv4_r.weight"), s.p("conv4_t.weight"),
+                         s.p("conv4_c.weight"), io.obj, t.K, h3->g.d, dz, B, N, Npad);
+      hipLaunchKernelGGL(head_final_wgrad_kernel, dim3(chunks, B), dim3(TB), 0, s.st, dz, h3->v.d, part, zpart, N, Npad, chunks);
+      hipLaunchKernelGGL(head_final_wgrad_finish_kernel, dim3(4), dim3(TB), 0, s.st, part, zpart, io.obj, t.K, s.gr("conv4_r.weight"), s.gr("conv4_r.bias"),
+                         s.gr("conv4_t.weight"), s.gr("conv4_t.bias"), s.gr("conv4_c.weight"), s.gr("conv4_c.bias"), B, N, chunks);
+    }
+  }
+  for (size_t i = s.tape.size(); i-- > 0;) {
+    s.tape[i]();
+    s.dbg("tape entry", std::to_string(i));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PoseRefineNet step (lib/network.py:151-206 + lib/loss_refiner.py:12-62): one refine iteration of B frames
+// ------------------------------------------------------------------------------------------------
+struct RefinerIO {
+  int B, M;
+  const float *points, *emb, *target, *model_points;      // [B][N][3], [B][32][N], [B][M][3], [B][M][3]
+  const int64_t *obj;
+  const int *symmetric;
+  float *dis, *new_points, *new_target;                   // [B], [B][N][3], [B][M][3]
+};
+
+void refiner_step(Step &s, const RefinerIO &io) {
+  Trainer &t = *s.t;
+  const int B = io.B, N = t.N, Npad = round_up(N, 128), rows = B * Npad;
+  Step *sp = &s;
+  s.splitk_bytes = (size_t)8 << 20;
+  s.splitk = static_cast<float *>(s.bytes(s.splitk_bytes));
+  Act *emb_pm = s.act(rows, 1, 1, 32);
+  if (s.live()) {
+    hipMemsetAsync(emb_pm->v.d, 0, (size_t)rows * 32 * sizeof(float), s.st);
+    launch_emb_to_pm(io.emb, emb_pm->v.d, B, N, Npad, s.st);
+  }
+  // pointfeat_3 = [x1 64 | e1 64 | x2 128 | e2 128] (lib/network.py:160-163)
+  Act *pf = s.act(rows, 1, 1, 384);
+  Act *x1 = slice(s, pf, 0, 64), *e1 = slice(s, pf, 64, 64), *x2 = slice(s, pf, 128, 128), *e2 = slice(s, pf, 256, 128);
+  if (s.live()) {
+    hipMemsetAsync(pf->v.d, 0, (size_t)rows * 384 * sizeof(float), s.st);
+    launch_cloud_conv1(io.points, nullptr, s.p("feat.conv1.weight"), s.p("feat.conv1.bias"), pf->v.d, 384, B, N, Npad, s.st);
+  }
+  s.tape.push_back([=]() {
+    Step &s = *sp;
+    Act m = *x1;
+    launch_act_bwd(s, &m, ACT_RELU, nullptr, nullptr);
+    const int chunks = (N + 255) / 256;
+    float *part = s.f((size_t)B * chunks * 64 * 4);
+    if (s.live()) {
+      hipLaunchKernelGGL(cloud_conv1_bwd_kernel, dim3(B * chunks), dim3(64), 0, s.st, x1->g.d, 384, io.points, B, N, Npad, part);
+      hipLaunchKernelGGL(cloud_conv1_bwd_finish_kernel, dim3(1), dim3(64), 0, s.st, part, B * chunks, s.gr("feat.conv1.weight"), s.gr("feat.conv1.bias"));
+    }
+  });
+  conv(s, emb_pm, 32, ConvW{"feat.e_conv1.weight", 0, "feat.e_conv1.bias"}, 64, 1, 1, 0, 1, ACT_RELU, nullptr, e1, false);
+  conv(s, x1, 64, ConvW{"feat.conv2.weight", 0, "feat.conv2.bias"}, 128, 1, 1, 0, 1, ACT_RELU, nullptr, x2);
+  conv(s, e1, 64, ConvW{"feat.e_conv2.weight", 0, "feat.e_conv2.bias"}, 128, 1, 1, 0, 1, ACT_RELU, nullptr, e2);
+  // conv5 reads all 384 channels: its data gradient is the first writer of pf's gradient buffer
+  Act *x5 = s.act(rows, 1, 1, 512);
+  {
+    ConvParams p5 = base_params(pf, 384, s.p("feat.conv5.weight"), s.p("feat.conv5.bias"), x5, 1, 1, 0, 1, ACT_RELU);
+    if (s.live()) s.fail(launch_conv(p5, s.st));
+    s.tape.push_back([=]() {
+      Step &s = *sp;
+      launch_act_bwd(s, x5, ACT_RELU, nullptr, nullptr);
+      wgrad(s, p5, x5->g, s.gr("feat.conv5.weight"), s.gr("feat.conv5.bias"));
+      s.grad_of(pf);
+      dgrad(s, p5, x5->g, pf->g, s.pf("feat.conv5.weight"), false);
+      Act *sl[4] = {x1, e1, x2, e2};
+      const int c0[4] = {0, 64, 128, 256};
+      for (int i = 0; i < 4; ++i) { sl[i]->g.d = pf->g.d + c0[i]; sl[i]->g.ld = 384; sl[i]->gset = true; }
+    });
+  }
+  Act *x6 = s.act(rows, 1, 1, 1024);
+  ConvParams p6 = base_params(x5, 512, s.p("feat.conv6.weight"), s.p("feat.conv6.bias"), x6, 1, 1, 0, 1, ACT_RELU);
+  p6.rows_per_group = Npad; p6.rows_valid = N;
+  int prow;
+  {
+    ConvParams q6 = p6;
+    q6.out = nullptr;            // (the partial-row count is that of the column-sum launch's tile, chosen when out is null or colsum set)
+    prow = conv_colsum_rows(q6);
+  }
+  float *partial = s.f((size_t)prow * 1024);
+  p6.colsum = partial;
+  if (s.live()) s.fail(launch_conv(p6, s.st));
+  Act *ap = s.act(B, 1, 1, 1024);
+  if (s.live()) launch_colsum_finish(partial, prow / B, ap->v.d, B, 1024, N, s.st);
+  s.tape.push_back([=]() {
+    Step &s = *sp;
+    s.grad_of(x6);
+    if (s.live()) hipLaunchKernelGGL(mask_bcast_kernel, dim3(nblk((long)rows * 256)), dim3(TB), 0, s.st, x6->v.d, ap->g.d, x6->g.d, B, N, Npad, 256);
+    ConvParams f = p6;
+    f.colsum = nullptr;
+    wgrad(s, f, x6->g, s.gr("feat.conv6.weight"), s.gr("feat.conv6.bias"));
+    s.grad_of(x5);
+    dgrad(s, f, x6->g, x5->g, s.pf("feat.conv6.weight"), false);
+  });
+  // FC towers 1024 -> 512 -> 128 (lib/network.py:191-196), one row per frame; f2 = [r 128 | t 128]
+  Act *f1 = s.act(B, 1, 1, 1024), *f2 = s.act(B, 1, 1, 256);
+  Act *f1r = slice(s, f1, 0, 512), *f1t = slice(s, f1, 512, 512), *f2r = slice(s, f2, 0, 128), *f2t = slice(s, f2, 128, 128);
+  s.tape.push_back([=]() {           // ap's gradient: r tower writes, t tower accumulates (conv() handles it through gset)
+  });
+  conv(s, ap, 1024, ConvW{"conv1_r.weight", 0, "conv1_r.bias"}, 512, 1, 1, 0, 1, ACT_RELU, nullptr, f1r);
+  conv(s, ap, 1024, ConvW{"conv1_t.weight", 0, "conv1_t.bias"}, 512, 1, 1, 0, 1, ACT_RELU, nullptr, f1t);
+  conv(s, f1r, 512, ConvW{"conv2_r.weight", 0, "conv2_r.bias"}, 128, 1, 1, 0, 1, ACT_RELU, nullptr, f2r);
+  conv(s, f1t, 512, ConvW{"conv2_t.weight", 0, "conv2_t.bias"}, 128, 1, 1, 0, 1, ACT_RELU, nullptr, f2t);
+  float *out_r = s.f((size_t)B * 4), *out_t = s.f((size_t)B * 3), *d_r = s.f((size_t)B * 4), *d_t = s.f((size_t)B * 3);
+  if (s.live())
+    hipLaunchKernelGGL(refiner_tail_fwd_kernel, dim3(B), dim3(64), 0, s.st, f2->v.d, s.p("conv3_r.weight"), s.p("conv3_r.bias"), s.p("conv3_t.weight"),
+                       s.p("conv3_t.bias"), io.obj, t.K, out_r, out_t, B);
+  int *sel = reinterpret_cast<int *>(s.bytes((size_t)B * io.M * sizeof(int)));
+  for (int b = 0; b < B && s.live(); ++b) {
+    const int sym = io.symmetric ? io.symmetric[b] : 0;
+    int *sb = sel + (size_t)b * io.M;
+    s.fail(df_loss_refine_forward(out_r + b * 4, out_t + b * 3, io.target + (size_t)b * io.M * 3, io.model_points + (size_t)b * io.M * 3,
+                                  io.points + (size_t)b * N * 3, N, io.M, sym, io.dis + b, io.new_points + (size_t)b * N * 3,
+                                  io.new_target + (size_t)b * io.M * 3, sym ? sb : nullptr, s.st));
+    s.fail(df_loss_refine_backward(out_r + b * 4, out_t + b * 3, io.target + (size_t)b * io.M * 3, io.model_points + (size_t)b * io.M * 3,
+                                   sym ? sb : nullptr, io.M, 1.f, d_r + b * 4, d_t + b * 3, s.st));
+  }
+  {
+    s.grad_of(f2);
+    f2r->g.d = f2->g.d; f2r->g.ld = 256; f2r->gset = true;
+    f2t->g.d = f2->g.d + 128; f2t->g.ld = 256; f2t->gset = true;
+    s.grad_of(f1);
+    f1r->g.d = f1->g.d; f1r->g.ld = 1024; f1r->gset = false;
+    f1t->g.d = f1->g.d + 512; f1t->g.ld = 1024; f1t->gset = false;
+    if (s.live())
+      hipLaunchKernelGGL(refiner_tail_bwd_kernel, dim3(1), dim3(128), 0, s.st, d_r, d_t, f2->v.d, s.p("conv3_r.weight"), s.p("conv3_t.weight"), io.obj, t.K,
+                         f2->g.d, s.gr("conv3_r.weight"), s.gr("conv3_r.bias"), s.gr("conv3_t.weight"), s.gr("conv3_t.bias"), B);
+  }
+  for (size_t i = s.tape.size(); i-- > 0;) {
+    s.tape[i]();
+    s.dbg("tape entry", std::to_string(i));
+  }
+}
+
+Trainer *as_trainer(df_trainer *h) { return reinterpret_cast<Trainer *>(h); }
+const Trainer *as_trainer(const df_trainer *h) { return reinterpret_cast<const Trainer *>(h); }
+
+}  // namespace
+}  // namespace df
+
+using namespace df;
+
+extern "C" df_trainer *df_trainer_create(int kind, int num_points, int num_obj) {
+  if ((kind != 0 && kind != 1) || num_points <= 0 || num_obj <= 0) { set_error(DF_ERR_ARG, "trainer_create: bad arguments"); return nullptr; }
+  Trainer *t = new Trainer();
+  t->kind = kind; t->N = num_points; t->K = num_obj;
+  hipGetDevice(&t->device);
+  if (kind == 0) build_posenet(*t);
+  else build_refiner(*t);
+  // the data gradients' flipped / transposed weight copies; without a device (layout / workspace queries on a CPU-only host) the
+  // handle still works for everything that launches nothing, and a step reports the missing arena
+  if (hipMalloc(&t->wflip, t->flat * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); t->wflip = nullptr; }
+  return reinterpret_cast<df_trainer *>(t);
+}
+
+extern "C" void df_trainer_destroy(df_trainer *h) {
+  if (!h) return;
+  Trainer *t = as_trainer(h);
+  if (t->wflip) hipFree(t->wflip);
+  delete t;
+}
+
+extern "C" int64_t df_trainer_flat_numel(const df_trainer *h) { return h ? (int64_t)as_trainer(h)->flat : 0; }
+extern "C" int df_trainer_num_params(const df_trainer *h) { return h ? (int)as_trainer(h)->spec.size() : 0; }
+
+extern "C" int df_trainer_param_info(const df_trainer *h, int i, char *key_out, int key_cap, int64_t *shape4, int *ndim) {
+  if (!h) return set_error(DF_ERR_ARG, "trainer_param_info: null handle");
+  const Trainer *t = as_trainer(h);
+  if (i < 0 || i >= (int)t->spec.size()) return set_error(DF_ERR_ARG, "trainer_param_info: index out of range");
+  const PSpec &p = t->spec[i];
+  if (key_out && key_cap > 0) { strncpy(key_out, p.key.c_str(), key_cap - 1); key_out[key_cap - 1] = 0; }
+  if (shape4) for (int d = 0; d < 4; ++d) shape4[d] = p.shape[d];
+  if (ndim) *ndim = p.ndim;
+  return DF_OK;
+}
+
+// dir 0: reference layout (`ref`, device) -> its place in the flat kernel-layout buffer; dir 1: back
+static int relayout(const Trainer &t, const char *key, float *ref, float *flat, int dir, hipStream_t st) {
+  if (!key || !ref || !flat) return set_error(DF_ERR_ARG, "trainer pack/unpack: null pointer");
+  auto it = t.index.find(key);
+  if (it == t.index.end()) return set_error(DF_ERR_ARG, "trainer pack/unpack: unexpected key '%s'", key);
+  const PSpec &p = t.spec[it->second];
+  if (p.mode == 0 || p.mode == 1) {
+    const int O = (int)p.shape[0], I = (int)p.shape[1], T = (int)(p.shape[2] * p.shape[3]), Ipad = p.mode == 0 ? (I + 3) / 4 * 4 : I;
+    hipLaunchKernelGGL(relayout_kernel, dim3(nblk((long)O * T * Ipad, 2048)), dim3(TB), 0, st, dir == 0 ? ref : flat + p.off, dir == 0 ? flat + p.off : ref, O, I, T,
+                       Ipad, p.mode, dir);
+  } else if (p.mode == 3) {       // [640][1408] <-> [640][384] + [640][1024]
+    if (dir == 0) {
+      hipLaunchKernelGGL(copy2d_kernel, dim3(nblk(640L * 384)), dim3(TB), 0, st, ref, 1408L, flat + p.off, 384L, 640L, 384L);
+      hipLaunchKernelGGL(copy2d_kernel, dim3(nblk(640L * 1024)), dim3(TB), 0, st, ref + 384, 1408L, flat + p.off2, 1024L, 640L, 1024L);
+    } else {
+      hipLaunchKernelGGL(copy2d_kernel, dim3(nblk(640L * 384)), dim3(TB), 0, st, flat + p.off, 384L, ref, 1408L, 640L, 384L);
+      hipLaunchKernelGGL(copy2d_kernel, dim3(nblk(640L * 1024)), dim3(TB), 0, st, flat + p.off2, 1024L, ref + 384, 1408L, 640L, 1024L);
+    }
+  } else {
+    const long n = (long)p.numel();
+    hipLaunchKernelGGL(copy2d_kernel, dim3(nblk(n)), dim3(TB), 0, st, dir == 0 ? ref : flat + p.off, n, dir == 0 ? flat + p.off : ref, n, 1L, n);
+  }
+  return check_launch("trainer pack/unpack");
+}
+
+extern "C" int df_trainer_pack_param(const df_trainer *h, const char *key, const float *src, float *flat, df_stream_t stream) {
+  if (!h) return set_error(DF_ERR_ARG, "trainer_pack_param: null handle");
+  return relayout(*as_trainer(h), key, const_cast<float *>(src), flat, 0, to_stream(stream));
+}
+extern "C" int df_trainer_unpack_param(const df_trainer *h, const char *key, const float *flat, float *dst, df_stream_t stream) {
+  if (!h) return set_error(DF_ERR_ARG, "trainer_unpack_param: null handle");
+  return relayout(*as_trainer(h), key, dst, const_cast<float *>(flat), 1, to_stream(stream));
+}
+
+extern "C" size_t df_posenet_train_workspace_bytes(const df_trainer *h, int B, int H, int W, int M) {
+  if (!h || as_trainer(h)->kind != 0 || B <= 0 || H < 8 || W < 8 || M <= 0) return 0;
+  Step s{const_cast<Trainer *>(as_trainer(h)), nullptr, true, nullptr};
+  PoseNetIO io{};
+  io.B = B; io.H = H; io.W = W; io.M = M; io.dropout = 1;
+  posenet_step(s, io);
+  return s.peak;
+}
+
+extern "C" int df_posenet_train_step(df_trainer *h, const float *flat_param, float *flat_grad, int64_t param_version, int B, int H, int W,
+                                     const float *img, const float *cloud, const int64_t *choose, const int64_t *obj, const float *target,
+                                     const float *model_points, int M, const int *symmetric_host, float w, int dropout, unsigned seed,
+                                     float *loss_out, float *dis_out, float *new_points, float *new_target, float *out_r, float *out_t,
+                                     float *out_c, float *emb, void *ws, size_t ws_bytes, df_stream_t stream) {
+  if (!h || as_trainer(h)->kind != 0) return set_error(DF_ERR_ARG, "posenet_train_step: not a PoseNet trainer");
+  if (B <= 0 || H < 8 || W < 8 || M <= 0) return set_error(DF_ERR_ARG, "posenet_train_step: need B >= 1, H, W >= 8, M >= 1");
+  if (!flat_param || !flat_grad || !img || !cloud || !choose || !obj || !target || !model_points || !loss_out || !dis_out || !ws)
+    return set_error(DF_ERR_ARG, "posenet_train_step: null pointer");
+  Trainer &t = *as_trainer(h);
+  if (df_posenet_train_workspace_bytes(h, B, H, W, M) > ws_bytes) return set_error(DF_ERR_WORKSPACE, "posenet_train_step: workspace too small");
+  int rc = check_flips(t, flat_param, (long)param_version, to_stream(stream));
+  if (rc != DF_OK) return rc;
+  Step s{&t, to_stream(stream), false, static_cast<char *>(ws)};
+  s.cap = ws_bytes; s.P = flat_param; s.G = flat_grad;
+  PoseNetIO io{B, H, W, M, img, cloud, target, model_points, choose, obj, symmetric_host, w, dropout, seed, loss_out, dis_out, new_points, new_target,
+               out_r, out_t, out_c, emb};
+  posenet_step(s, io);
+  if (s.err != DF_OK) return s.err;
+  return check_launch("posenet_train_step");
+}
+
+extern "C" size_t df_refiner_train_workspace_bytes(const df_trainer *h, int B, int M) {
+  if (!h || as_trainer(h)->kind != 1 || B <= 0 || M <= 0) return 0;
+  Step s{const_cast<Trainer *>(as_trainer(h)), nullptr, true, nullptr};
+  RefinerIO io{};
+  io.B = B; io.M = M;
+  refiner_step(s, io);
+  return s.peak;
+}
+
+extern "C" int df_refiner_train_step(df_trainer *h, const float *flat_param, float *flat_grad, int64_t param_version, int B, const float *points,
+                                     const float *emb, const int64_t *obj, const float *target, const float *model_points, int M,
+                                     const int *symmetric_host, float *dis_out, float *new_points, float *new_target, void *ws, size_t ws_bytes,
+                                     df_stream_t stream) {
+  if (!h || as_trainer(h)->kind != 1) return set_error(DF_ERR_ARG, "refiner_train_step: not a PoseRefineNet trainer");
+  if (B <= 0 || M <= 0) return set_error(DF_ERR_ARG, "refiner_train_step: need B >= 1, M >= 1");
+  if (!flat_param || !flat_grad || !points || !emb || !obj || !target || !model_points || !dis_out || !new_points || !new_target || !ws)
+    return set_error(DF_ERR_ARG, "refiner_train_step: null pointer");
+  Trainer &t = *as_trainer(h);
+  if (df_refiner_train_workspace_bytes(h, B, M) > ws_bytes) return set_error(DF_ERR_WORKSPACE, "refiner_train_step: workspace too small");
+  int rc = check_flips(t, flat_param, (long)param_version, to_stream(stream));
+  if (rc != DF_OK) return rc;
+  Step s{&t, to_stream(stream), false, static_cast<char *>(ws)};
+  s.cap = ws_bytes; s.P = flat_param; s.G = flat_grad;
+  RefinerIO io{B, M, points, emb, target, model_points, obj, symmetric_host, dis_out, new_points, new_target};
+  refiner_step(s, io);
+  if (s.err != DF_OK) return s.err;
+  return check_launch("refiner_train_step");
+}

@@ -1,0 +1,173 @@
+"""Host side of the native training step (``df_posenet_train_step`` / ``df_refiner_train_step``, csrc/train.hip).
+
+``NativeTrainer(kind, num_points, num_obj, device)`` owns the two flat fp32 buffers a training run needs -- parameters and
+accumulated gradients, both in the library's KERNEL layout -- and exposes what tools/train.py does with a network
+(reference: tools/train.py:78-99,146-176):
+
+* ``load_state_dict`` / ``state_dict``: the reference's keys and shapes (``torch.save(estimator.state_dict())`` files load
+  unchanged); the conversion to / from the kernel layout happens only here.
+* ``step_posenet(...)`` / ``step_refiner(...)``: forward + loss + backward of B same-size frames in ONE library call --
+  no autograd tape, no per-layer Python, nothing read back; gradients are accumulated into ``.grad``.
+* ``.data`` / ``.grad`` / ``.numel`` / ``zero_grad()``: the interface ``train_utils.FlatAdam`` and
+  ``train_utils.allreduce_gradients`` already work on (Adam and the all-reduce are layout-agnostic).
+
+PyTorch only provides the device memory and the stream.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+POSENET, REFINER = 0, 1
+
+
+class NativeTrainer:
+    def __init__(self, kind, num_points, num_obj, device):
+        self.kind = POSENET if kind in (POSENET, "posenet") else REFINER
+        self.num_points, self.num_obj = int(num_points), int(num_obj)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("densefusion_amd needs a GPU device (no CPU path)")
+        L = _lib.lib()
+        with _lib.device_guard(self.device):
+            self._h = L.df_trainer_create(self.kind, self.num_points, self.num_obj)
+        if not self._h:
+            _lib.check(-1, "trainer_create")
+        self.numel = int(L.df_trainer_flat_numel(self._h))
+        self.data = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        self.version = 0                     # bumped whenever .data changes (optimizer step, load_state_dict)
+        self.module = None                   # (FlatAdam looks for an nn.Module to invalidate; there is none)
+        self._ws = None
+        self._calls = 0
+        self.spec = []
+        key, shape, ndim = ctypes.create_string_buffer(256), (ctypes.c_int64 * 4)(), ctypes.c_int()
+        for i in range(L.df_trainer_num_params(self._h)):
+            _lib.check(L.df_trainer_param_info(self._h, i, key, 256, shape, ctypes.byref(ndim)), "trainer_param_info")
+            self.spec.append((key.value.decode(), tuple(int(shape[d]) for d in range(ndim.value))))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().df_trainer_destroy(self._h)
+                self._h = None
+        except Exception:        # noqa: BLE001
+            pass
+
+    # ---- checkpoints: the reference's keys / shapes ----
+    def load_state_dict(self, sd, strict=True):
+        L = _lib.lib()
+        missing = [k for k, _ in self.spec if k not in sd]
+        extra = [k for k in sd if k not in dict(self.spec)]
+        if strict and (missing or extra):
+            raise RuntimeError(f"load_state_dict: missing keys {missing[:4]}, unexpected keys {extra[:4]}")
+        with _lib.device_guard(self.device):
+            for k, shape in self.spec:
+                if k not in sd:
+                    continue
+                t = sd[k].detach().to(device=self.device, dtype=torch.float32).contiguous()
+                if tuple(t.shape) != shape:
+                    raise RuntimeError(f"load_state_dict: {k} has shape {tuple(t.shape)}, expected {shape}")
+                _lib.check(L.df_trainer_pack_param(self._h, k.encode(), t.data_ptr(), self.data.data_ptr(), _lib.current_stream()), "trainer_pack_param")
+        torch.cuda.current_stream(self.device).synchronize()          # the staging tensors above die here
+        self.version += 1
+
+    def _unpack(self, flat):
+        L = _lib.lib()
+        out = {}
+        with _lib.device_guard(self.device):
+            for k, shape in self.spec:
+                t = torch.zeros(shape, dtype=torch.float32, device=self.device)
+                _lib.check(L.df_trainer_unpack_param(self._h, k.encode(), flat.data_ptr(), t.data_ptr(), _lib.current_stream()), "trainer_unpack_param")
+                out[k] = t
+        return out
+
+    def state_dict(self):
+        return self._unpack(self.data)
+
+    def grad_dict(self):
+        """The accumulated gradients in the reference's layout (tests / inspection)."""
+        return self._unpack(self.grad)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def bump_version(self):
+        self.version += 1
+
+    def _workspace(self, need):
+        if need == 0:
+            _lib.check(-1, "train_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    @staticmethod
+    def _sym(sym_host, B):
+        if sym_host is None:
+            return None
+        vals = [int(bool(v)) for v in sym_host]
+        if len(vals) != B:
+            raise RuntimeError("symmetric flags: one per frame")
+        return (ctypes.c_int * B)(*vals)
+
+    # ---- PoseNet + Loss (tools/train.py:152-153,161) ----
+    def step_posenet(self, img, cloud, choose, obj, target, model_points, symmetric, w, dropout=True, seed=None, want_pred=False,
+                     graph_safe=False):
+        """img [B,3,H,W], cloud [B,N,3], choose [B,N]|[B,1,N], obj [B]|[B,1] (device), target / model_points [B,M,3];
+        symmetric: HOST booleans, one per frame (``idx in sym_list``).  -> dict(loss [B], dis [B], new_points [B,N,3],
+        new_target [B,M,3], emb [B,32,N] (+ pred_r / pred_t / pred_c when want_pred)).  Gradients of sum_b loss[b] are ADDED to .grad."""
+        assert self.kind == POSENET
+        f32 = lambda t: t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        img, cloud, target, model_points = f32(img), f32(cloud), f32(target), f32(model_points)
+        B, _, H, W = img.shape
+        N, M = self.num_points, target.shape[-2]
+        if cloud.shape != (B, N, 3) or target.numel() != B * M * 3 or model_points.numel() != B * M * 3:
+            raise RuntimeError(f"step_posenet: expected cloud [{B},{N},3] and target / model_points [{B},M,3]")
+        choose = choose.to(device=self.device, dtype=torch.int64).reshape(B, N).contiguous()
+        obj = obj.to(device=self.device, dtype=torch.int64).reshape(B).contiguous()
+        dev = self.device
+        out = dict(loss=torch.empty(B, device=dev), dis=torch.empty(B, device=dev), new_points=torch.empty(B, N, 3, device=dev),
+                   new_target=torch.empty(B, M, 3, device=dev), emb=torch.empty(B, 32, N, device=dev))
+        if want_pred:
+            out.update(pred_r=torch.empty(B, N, 4, device=dev), pred_t=torch.empty(B, N, 3, device=dev), pred_c=torch.empty(B, N, 1, device=dev))
+        self._calls += 1
+        if seed is None:
+            seed = (int(torch.initial_seed() % 100003) * 7919 + self._calls) & 0x3FFFFFFF
+        P = lambda k: out[k].data_ptr() if k in out else None
+        L = _lib.lib()
+        with _lib.device_guard(dev):
+            ws = self._workspace(L.df_posenet_train_workspace_bytes(self._h, B, H, W, M))
+            st = L.df_posenet_train_step(self._h, self.data.data_ptr(), self.grad.data_ptr(), -1 if graph_safe else self.version, B, H, W,
+                                         img.data_ptr(), cloud.data_ptr(), choose.data_ptr(), obj.data_ptr(), target.data_ptr(),
+                                         model_points.data_ptr(), M, self._sym(symmetric, B), float(w), int(bool(dropout)), int(seed) & 0xFFFFFFFF,
+                                         P("loss"), P("dis"), P("new_points"), P("new_target"), P("pred_r"), P("pred_t"), P("pred_c"), P("emb"),
+                                         ws.data_ptr(), ws.numel(), _lib.current_stream())
+        _lib.check(st, "posenet_train_step")
+        return out
+
+    # ---- PoseRefineNet + Loss_refine (tools/train.py:156-159) ----
+    def step_refiner(self, points, emb, obj, target, model_points, symmetric, graph_safe=False):
+        """One refine iteration: points [B,N,3] (in the current pose's frame), emb [B,32,N], target / model_points [B,M,3]
+        -> dict(dis [B], new_points, new_target).  Gradients of sum_b dis[b] are ADDED to .grad."""
+        assert self.kind == REFINER
+        f32 = lambda t: t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        points, emb, target, model_points = f32(points), f32(emb), f32(target), f32(model_points)
+        B, N, M = points.shape[0], self.num_points, target.shape[-2]
+        if points.shape != (B, N, 3) or emb.shape != (B, 32, N):
+            raise RuntimeError(f"step_refiner: expected points [{B},{N},3], emb [{B},32,{N}]")
+        obj = obj.to(device=self.device, dtype=torch.int64).reshape(B).contiguous()
+        dev = self.device
+        out = dict(dis=torch.empty(B, device=dev), new_points=torch.empty(B, N, 3, device=dev), new_target=torch.empty(B, M, 3, device=dev))
+        L = _lib.lib()
+        with _lib.device_guard(dev):
+            ws = self._workspace(L.df_refiner_train_workspace_bytes(self._h, B, M))
+            st = L.df_refiner_train_step(self._h, self.data.data_ptr(), self.grad.data_ptr(), -1 if graph_safe else self.version, B, points.data_ptr(),
+                                         emb.data_ptr(), obj.data_ptr(), target.data_ptr(), model_points.data_ptr(), M, self._sym(symmetric, B),
+                                         out["dis"].data_ptr(), out["new_points"].data_ptr(), out["new_target"].data_ptr(), ws.data_ptr(),
+                                         ws.numel(), _lib.current_stream())
+        _lib.check(st, "refiner_train_step")
+        return out

@@ -84,6 +84,8 @@ class FlatAdam:
         # the update bypasses torch's version counters: tell the inference engine its parameter copies are stale
         if hasattr(f.module, "_uploaded"):
             f.module._uploaded = {}
+        if hasattr(f, "bump_version"):          # NativeTrainer: its cached data-gradient weight copies are stale now
+            f.bump_version()
 
 
 def with_host_index(t_dev, values):

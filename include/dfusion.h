@@ -246,6 +246,45 @@ size_t df_conv2d_wgrad_workspace_bytes(const df_conv_desc *d);
 int df_conv2d_wgrad_nhwc(const df_conv_desc *d, const float *dy, float *dw, float *db, void *ws, size_t ws_bytes,
                          df_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Native training step (replaces the loop body of tools/train.py:146-163 of the reference: estimator / refiner forward,
+ * criterion, loss.backward()) for B same-size frames, sequenced in C++ on one stream: no host synchronisation, no allocation,
+ * every launch capturable in a hipGraph.  Parameters and gradients live in ONE flat fp32 buffer each, owned by the caller, in
+ * KERNEL layout (conv O(HW)I, up_1 / up_2 tap-major, head layer 1 split, towers stacked); df_trainer_pack_param /
+ * df_trainer_unpack_param convert a tensor from / to the reference's state-dict layout (same keys and shapes as
+ * df_net_param_info), so checkpoints keep the reference's format.  Gradients are ACCUMULATED into flat_grad (loss.backward()
+ * per frame, optimizer.step() every batch_size frames, tools/train.py:161-169) with fixed-order reductions only: two
+ * identical steps give bit-identical gradient buffers.  param_version: any number that changes whenever flat_param's contents
+ * change (the optimizer step count): the flipped weight copies of the data gradients are rebuilt only then; pass -1 to
+ * rebuild them in every step (what a captured graph needs).
+ *   kind 0: PoseNet + Loss (lib/network.py:95-132, lib/loss.py:13-70);  kind 1: PoseRefineNet + Loss_refine
+ *   (lib/network.py:187-206, lib/loss_refiner.py:12-62).
+ * df_posenet_train_step: img [B][3][H][W], cloud [B][N][3], choose [B][N] int64, obj [B] int64 (device), target /
+ *   model_points [B][M][3], symmetric_host [B] (HOST ints or NULL: which frames take the nearest-neighbour branch),
+ *   dropout != 0: Dropout2d of lib/pspnet.py:46,52 with masks hashed from `seed`;  outputs loss_out [B], dis_out [B],
+ *   optional new_points [B][N][3], new_target [B][M][3], out_r [B][N][4], out_t [B][N][3], out_c [B][N], emb [B][32][N].
+ * df_refiner_train_step: one refine iteration: points [B][N][3] (already in the current pose's frame), emb [B][32][N] ->
+ *   dis_out [B], new_points, new_target for the next iteration. */
+typedef struct df_trainer df_trainer;
+df_trainer *df_trainer_create(int kind, int num_points, int num_obj);
+void df_trainer_destroy(df_trainer *t);
+int64_t df_trainer_flat_numel(const df_trainer *t);
+int df_trainer_num_params(const df_trainer *t);
+int df_trainer_param_info(const df_trainer *t, int i, char *key_out, int key_cap, int64_t *shape4, int *ndim);
+int df_trainer_pack_param(const df_trainer *t, const char *key, const float *src, float *flat, df_stream_t stream);
+int df_trainer_unpack_param(const df_trainer *t, const char *key, const float *flat, float *dst, df_stream_t stream);
+size_t df_posenet_train_workspace_bytes(const df_trainer *t, int B, int H, int W, int M);
+int df_posenet_train_step(df_trainer *t, const float *flat_param, float *flat_grad, int64_t param_version, int B, int H, int W,
+                          const float *img, const float *cloud, const int64_t *choose, const int64_t *obj, const float *target,
+                          const float *model_points, int M, const int *symmetric_host, float w, int dropout, unsigned seed,
+                          float *loss_out, float *dis_out, float *new_points, float *new_target, float *out_r, float *out_t,
+                          float *out_c, float *emb, void *ws, size_t ws_bytes, df_stream_t stream);
+size_t df_refiner_train_workspace_bytes(const df_trainer *t, int B, int M);
+int df_refiner_train_step(df_trainer *t, const float *flat_param, float *flat_grad, int64_t param_version, int B, const float *points,
+                          const float *emb, const int64_t *obj, const float *target, const float *model_points, int M,
+                          const int *symmetric_host, float *dis_out, float *new_points, float *new_target, void *ws, size_t ws_bytes,
+                          df_stream_t stream);
+
 /* Per-launch timing of the GEMM kernel with HIP events on the call's stream (bench.py roofline).
  * df_net_profile(net, 1) arms it; after the stream has been synchronised df_net_profile_read returns the
  * summed duration (ms), the FLOPs the launches perform (2 M N K per launch, M = the rows launched), the part of them spent on

@@ -1,0 +1,225 @@
+"""GPU: the native training step (df_posenet_train_step / df_refiner_train_step, csrc/train.hip) -- forward + loss + backward
+of B frames in ONE library call -- against torch CPU autograd through the oracle restatement, against the imported
+reference's own backward (tests/golden/grad_tiny.npz), and for the properties the flat-buffer design promises: gradients
+accumulate over frames like separate bs = 1 passes, two identical steps give bit-identical gradient buffers, the state dict
+round-trips through the kernel layout, the step replays from a hipGraph."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from densefusion_amd import synth
+from oracle import dfnet, loss_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _close(a, b, rtol, name=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    scale = max(b.abs().max().item(), 1e-12)
+    err = (a - b).abs().max().item()
+    assert err <= rtol * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def _trainer(kind, N, K, sd):
+    from densefusion_amd.native_train import NativeTrainer
+    tr = NativeTrainer(kind, N, K, DEV)
+    tr.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return tr
+
+
+def _frames(objs, keys=("img", "cloud", "choose", "obj", "target", "model_points")):
+    return {k: torch.stack([torch.from_numpy(o[k]) for o in objs]).to(DEV) for k in keys}
+
+
+def test_state_dict_round_trips_through_the_kernel_layout():
+    K, N = 3, 64
+    for kind, spec, seed in (("posenet", synth.posenet_spec(K), 5), ("refiner", synth.refiner_spec(K), 6)):
+        sd = synth.make_state_dict(spec, seed)
+        tr = _trainer(kind, N, K, sd)
+        back = tr.state_dict()
+        assert list(back) == list(sd)                      # the reference's keys, in its order
+        for k, v in sd.items():
+            assert tuple(back[k].shape) == v.shape and torch.equal(back[k].cpu(), torch.from_numpy(v)), k
+    with pytest.raises(RuntimeError):
+        tr.load_state_dict({"feat.conv1.weight": torch.zeros(64, 3, 1)})       # strict: missing keys
+
+
+@pytest.mark.parametrize("sym", [False, True])
+def test_posenet_step_matches_oracle_autograd(sym):
+    K, N, H, W, M = 2, 64, 40, 40, 60
+    sd = synth.make_state_dict(synth.posenet_spec(K), 11)
+    o = synth.make_object(101, H, W, N, K, num_points_mesh=M)
+    o["obj"][0] = 1 if sym else 0
+    idx = torch.tensor([[int(o["obj"][0])]])
+    T = lambda k: torch.from_numpy(o[k])[None]
+    psd = {k: torch.from_numpy(v).clone().requires_grad_() for k, v in sd.items()}
+    r, t, c, emb = dfnet.posenet_forward(psd, T("img"), T("cloud"), torch.from_numpy(o["choose"]), idx)
+    want_loss, want_dis, want_np, want_nt = loss_ref.loss_calculation(r, t, c, T("target"), T("model_points"), idx, T("cloud"), 0.015, False, M, [1])
+    want_loss.backward()
+    tr = _trainer("posenet", N, K, sd)
+    f = _frames([o])
+    out = tr.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], [sym], 0.015, dropout=False, want_pred=True)
+    _close(out["pred_r"], r, 2e-4, "pred_r"); _close(out["pred_c"], c, 2e-4, "pred_c"); _close(out["emb"], emb, 2e-4, "emb")
+    _close(out["loss"], want_loss.reshape(1), 1e-4, "loss"); _close(out["dis"], want_dis.reshape(1), 1e-4, "dis")
+    _close(out["new_points"], want_np, 1e-4, "new_points"); _close(out["new_target"], want_nt, 1e-4, "new_target")
+    got = tr.grad_dict()
+    checked = 0
+    for key, g in got.items():
+        want = psd[key].grad
+        if "classifier" in key:
+            assert float(g.abs().max()) == 0.0                 # dead weights get no gradient
+            continue
+        assert want is not None, key
+        _close(g, want, 2e-3, key)
+        checked += 1
+    assert checked >= 70
+
+
+def test_refiner_step_matches_oracle_autograd():
+    K, N, M = 2, 64, 60
+    sd = synth.make_state_dict(synth.refiner_spec(K), 1011)
+    o = synth.make_object(103, 40, 40, N, K, num_points_mesh=M)
+    o["obj"][0] = 1
+    emb = torch.from_numpy(np.random.default_rng(0).standard_normal((1, 32, N)).astype(np.float32))
+    idx = torch.tensor([[1]])
+    T = lambda k: torch.from_numpy(o[k])[None]
+    psd = {k: torch.from_numpy(v).clone().requires_grad_() for k, v in sd.items()}
+    pr, pt = dfnet.refiner_forward(psd, T("cloud"), emb, idx)
+    want, want_np, want_nt = loss_ref.loss_refine_calculation(pr, pt, T("target"), T("model_points"), idx, T("cloud"), M, [1])
+    want.backward()
+    tr = _trainer("refiner", N, K, sd)
+    out = tr.step_refiner(T("cloud").to(DEV), emb.to(DEV), idx.to(DEV), T("target").to(DEV), T("model_points").to(DEV), [True])
+    _close(out["dis"], want.reshape(1), 1e-4, "dis"); _close(out["new_points"], want_np, 1e-4, "new_points")
+    _close(out["new_target"], want_nt, 1e-4, "new_target")
+    for key, g in tr.grad_dict().items():
+        _close(g, psd[key].grad, 2e-3, key)
+
+
+def test_native_step_matches_the_references_backward():
+    """tests/golden/grad_tiny.npz: the imported reference's Loss(...).backward() through its PoseNet (oracle/make_golden.py)."""
+    from oracle.make_golden import grad_sample
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "grad_tiny.npz"))
+    K, N, H, W, M, wseed, iseed, idx0 = [int(v) for v in g["meta"]]
+    o = synth.make_object(iseed, H, W, N, K, num_points_mesh=M)
+    o["obj"][0] = idx0
+    tr = _trainer("posenet", N, K, synth.make_state_dict(synth.posenet_spec(K), wseed))
+    f = _frames([o])
+    out = tr.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], [False], 0.015, dropout=False, want_pred=True)
+    _close(out["pred_r"], torch.from_numpy(g["out_rx"]), 2e-4, "out_rx"); _close(out["pred_c"], torch.from_numpy(g["out_cx"]), 2e-4, "out_cx")
+    _close(out["loss"], torch.from_numpy(g["loss"]).reshape(1), 1e-4, "loss"); _close(out["dis"], torch.from_numpy(g["dis"]).reshape(1), 1e-4, "dis")
+    grads = tr.grad_dict()
+    keys = [k[5:] for k in g.files if k.startswith("grad:")]
+    assert len(keys) == 20
+    for k in keys:
+        _close(torch.from_numpy(grad_sample(grads[k].cpu().numpy())), torch.from_numpy(g["grad:" + k]), 2e-3, k)
+
+
+def test_batched_step_accumulates_like_separate_frames_and_is_bit_reproducible():
+    """B frames in one step == the same frames one per step (gradients accumulate in .grad, tools/train.py:161-169), with the
+    Dropout2d masks on (same seed -> same masks per frame index is NOT promised across batchings, so dropout is off for that
+    comparison); two identical steps leave bit-identical gradient buffers, dropout on, symmetric and plain frames mixed."""
+    K, N, H, W, M, B = 3, 128, 40, 80, 60, 3
+    sd = synth.make_state_dict(synth.posenet_spec(K), 17)
+    objs = [synth.make_object(300 + i, H, W, N, K, num_points_mesh=M) for i in range(B)]
+    for i, o in enumerate(objs):
+        o["obj"][0] = i % K
+    sym = [int(o["obj"][0]) == 1 for o in objs]
+    f = _frames(objs)
+    tr = _trainer("posenet", N, K, sd)
+    a = tr.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], sym, 0.015, dropout=False)
+    g_batched = tr.grad.clone()
+    tr.zero_grad()
+    for b in range(B):
+        s = slice(b, b + 1)
+        o1 = tr.step_posenet(f["img"][s], f["cloud"][s], f["choose"][s], f["obj"][s], f["target"][s], f["model_points"][s], sym[s], 0.015, dropout=False)
+        _close(o1["loss"], a["loss"][s], 1e-5, "loss"); _close(o1["new_points"], a["new_points"][s], 1e-5, "new_points")
+    _close(tr.grad, g_batched, 5e-4, "flat gradient")
+    runs = []
+    for _ in range(2):
+        tr.zero_grad()
+        tr.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], sym, 0.015, dropout=True, seed=77)
+        runs.append(tr.grad.clone())
+    assert torch.equal(runs[0], runs[1]) and float(runs[0].abs().sum()) > 0
+    tr.zero_grad()
+    tr.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], sym, 0.015, dropout=True, seed=78)
+    assert not torch.equal(tr.grad, runs[0])                      # another seed, other masks
+    # refiner: same two statements
+    trr = _trainer("refiner", N, K, synth.make_state_dict(synth.refiner_spec(K), 1017))
+    emb = a["emb"]
+    r1 = trr.step_refiner(a["new_points"], emb, f["obj"], a["new_target"], f["model_points"], sym)
+    gb = trr.grad.clone()
+    trr.zero_grad()
+    for b in range(B):
+        s = slice(b, b + 1)
+        trr.step_refiner(a["new_points"][s], emb[s], f["obj"][s], a["new_target"][s], f["model_points"][s], sym[s])
+    _close(trr.grad, gb, 5e-4, "refiner flat gradient")
+    trr.zero_grad()
+    trr.step_refiner(a["new_points"], emb, f["obj"], a["new_target"], f["model_points"], sym)
+    assert torch.equal(trr.grad, gb) and float(r1["dis"].min()) > 0
+
+
+def test_native_step_at_the_ycb_training_shape_with_adam_and_a_hipgraph():
+    """BASELINE configs[3] sizes (K = 21, N = 1000, M = 500, a symmetric object: the 250 M-pair nearest-neighbour branch): the
+    native step agrees with the autograd-tape training path (densefusion_amd/lib/train_graph.py, itself held to the oracle and
+    to the reference's backward), an Adam update on the flat buffers changes the next loss, and the whole step replays from a
+    hipGraph with the gradients it produced eagerly."""
+    from densefusion_amd import train_utils
+    from densefusion_amd.lib import train_graph
+    from densefusion_amd.lib.loss import Loss
+    from densefusion_amd.lib.network import PoseNet
+    K, N, H, W, M = 21, 1000, 80, 120, 500
+    sym_list = [12, 15, 18, 19, 20]
+    sd = synth.make_state_dict(synth.posenet_spec(K), 13)
+    objs = [synth.make_object(105 + i, H, W, N, K, num_points_mesh=M) for i in range(2)]
+    objs[0]["obj"][0], objs[1]["obj"][0] = 15, 3
+    sym = [True, False]
+    f = _frames(objs)
+    net = PoseNet(N, K)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.to(DEV).train()
+    r, t, c, _ = train_graph.posenet_forward(net, f["img"], f["cloud"], f["choose"], f["obj"], dropout=False)
+    crit = Loss(M, sym_list)
+    total = 0
+    for b in range(2):
+        ob = train_utils.with_host_index(f["obj"][b:b + 1], objs[b]["obj"])
+        total = total + crit(r[b:b + 1], t[b:b + 1], c[b:b + 1], f["target"][b:b + 1], f["model_points"][b:b + 1], ob, f["cloud"][b:b + 1], 0.015, False)[0]
+    total.backward()
+    tr = _trainer("posenet", N, K, sd)
+    out = tr.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], sym, 0.015, dropout=False)
+    _close(out["loss"].sum(), total, 1e-4, "loss")
+    got = tr.grad_dict()
+    for key, p in net.named_parameters():
+        if "classifier" in key:
+            continue
+        _close(got[key], p.grad, 2e-3, key)
+    eager = tr.grad.clone()
+    # the same step from a hipGraph (graph_safe: the data-gradient weight copies are rebuilt inside the captured step)
+    tr.zero_grad()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        tr.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], sym, 0.015, dropout=False, graph_safe=True)
+    torch.cuda.current_stream().wait_stream(side)
+    tr.zero_grad()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        captured = tr.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], sym, 0.015, dropout=False,
+                                   graph_safe=True)
+    tr.zero_grad()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(tr.grad, eager)
+    _close(captured["loss"], out["loss"], 1e-6, "replayed loss")
+    # one Adam step on the flat buffers (kernel layout: Adam is element-wise) lowers this batch's loss
+    opt = train_utils.FlatAdam(tr, lr=1e-4)
+    v0 = tr.version
+    opt.step(grad_scale=0.5)
+    assert tr.version == v0 + 1
+    tr.zero_grad()
+    out2 = tr.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], sym, 0.015, dropout=False)
+    assert float(out2["loss"].sum()) < float(out["loss"].sum())
