@@ -373,71 +373,135 @@ def bench_entry_point(est, ref, device, windows=9, frames=56):
 
 def bench_train(device):
     """BASELINE configs[3] per GPU: YCB training step, K=21, N=1000, M=500 (PoseNet phase), symmetric KNN loss on half of the
-    frames, 8 frames accumulated per optimizer step (tools/train.py:131-170), every layer's forward / data gradient / weight
-    gradient a HIP launch (densefusion_amd/lib/train_graph.py).  frames/s with the reference's bs = 1 passes and with the 8
-    frames of an accumulation window sharing one pass (same gradients); per-kernel-kind TFLOP/s from HIP events around the
-    conv launches of an instrumented pass."""
+    frames, 8 frames accumulated per optimizer step (tools/train.py:131-170).  The step is the NATIVE one (csrc/train.hip:
+    forward + loss + backward of the frames of a pass in one library call, gradients accumulated in the flat kernel-layout
+    buffer, Adam on that buffer): frames/s with the reference's bs = 1 passes (one call per frame; eager, and with the frames of
+    a window on `streams` HIP streams, each accumulating into its own gradient buffer, summed in a fixed order before the
+    optimizer step) and with the 8 frames of a window sharing one pass.  `autograd_tape`: the round-2 path (every layer a
+    Python autograd Function) on the same frames, with its per-kernel-kind TFLOP/s from HIP events around the conv launches."""
     from densefusion_amd import train_ops, train_utils
     from densefusion_amd.lib.loss import Loss
+    from densefusion_amd.native_train import NativeTrainer
     K, N, M, acc = K_OBJ, N_PTS, 500, 8
-    net = PoseNet(N, K)
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.posenet_spec(K), WSEED).items()})
-    net.to(device).train()
-    flat = train_utils.FlatParams(net)
-    opt = train_utils.FlatAdam(flat, lr=1e-4)
-    crit = Loss(M, [12, 15, 18, 19, 20])
+    sym_list = [12, 15, 18, 19, 20]
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.posenet_spec(K), WSEED).items()}
     H, W = 160, 160
-    frames = []
+    objs = []
     for j in range(acc):
         o = synth.make_object(500 + j, H, W, N, K, M)
         o["obj"][0] = [12, 3, 15, 7][j % 4]                         # every other frame is a symmetric object (KNN loss branch)
-        fd = {k: torch.from_numpy(v).to(device) for k, v in o.items()}
-        train_utils.with_host_index(fd["obj"], o["obj"])           # what a data loader does: the losses branch on the index without a read-back
-        frames.append(fd)
+        objs.append(o)
+    sym = [int(o["obj"][0]) in sym_list for o in objs]
+    fr = {k: torch.stack([torch.from_numpy(o[k]) for o in objs]).to(device) for k in ("img", "cloud", "choose", "obj", "target", "model_points")}
+    tr = NativeTrainer("posenet", N, K, device)
+    tr.load_state_dict(sd)
+    opt = train_utils.FlatAdam(tr, lr=1e-4)
+    nstreams = int(os.environ.get("DF_BENCH_TRAIN_STREAMS", "4"))
+    lanes = [NativeTrainer("posenet", N, K, device) for _ in range(nstreams - 1)]       # extra lanes: own workspace + gradient buffer
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=nstreams)
 
-    def step(fr):
-        with train_ops.splitk_scope(device):             # one registration of the split-K scratch per pass (tools/train.py does the same)
-            return _step(fr)
+    def frames(sl):
+        return [fr[k][sl] for k in ("img", "cloud", "choose", "obj", "target", "model_points")]
 
-    def _step(fr):
-        img = torch.stack([f["img"] for f in fr]); cloud = torch.stack([f["cloud"] for f in fr])
-        choose = torch.stack([f["choose"] for f in fr]); obj = torch.stack([f["obj"] for f in fr])
-        r, t, c, emb = net(img, cloud, choose, obj)
-        loss = 0
-        for b, f in enumerate(fr):
-            loss = loss + crit(r[b:b + 1], t[b:b + 1], c[b:b + 1], f["target"][None], f["model_points"][None], f["obj"], f["cloud"][None],
-                               0.015, False)[0]
-        loss.backward()
+    def window(P, multi=False):
+        if P == 1 and multi:
+            main = torch.cuda.current_stream()
 
-    def window(P):
-        for i in range(0, acc, P):
-            step(frames[i:i + P])
-        train_utils.allreduce_gradients(flat); opt.step(); flat.zero_grad()
+            def lane_work(li):           # one host thread per lane: the library call releases the GIL, launches are issued in parallel
+                torch.cuda.set_device(device)
+                lane = tr if li == 0 else lanes[li - 1]
+                with torch.cuda.stream(streams[li]):
+                    if li:
+                        lane.data, lane.version = tr.data, tr.version            # every lane reads the same parameters
+                    for i in range(li, acc, nstreams):
+                        lane.step_posenet(*frames(slice(i, i + 1)), sym[i:i + 1], 0.015, dropout=True)
 
-    out = {"workload": f"YCB training step, K={K}, N={N}, M={M}, crop {H}x{W}, {acc} frames per optimizer step, fp32", "frames_per_s": {}}
-    for P in (1, acc):
-        window(P)
+            for st in streams:
+                st.wait_stream(main)
+            for fut in [pool.submit(lane_work, li) for li in range(nstreams)]:
+                fut.result()
+            for st in streams:
+                main.wait_stream(st)
+            for lane in lanes:                                                       # fixed order: lane 1, 2, ...
+                tr.grad.add_(lane.grad)
+                lane.grad.zero_()
+        else:
+            for i in range(0, acc, P):
+                tr.step_posenet(*frames(slice(i, i + P)), sym[i:i + P], 0.015, dropout=True)
+        train_utils.allreduce_gradients(tr); opt.step(grad_scale=1.0 / acc); tr.zero_grad()
+
+    out = {"workload": f"YCB training step, K={K}, N={N}, M={M}, crop {H}x{W}, {acc} frames per optimizer step, fp32, native step (csrc/train.hip)",
+           "frames_per_s": {}}
+    for name, P, multi in (("1_per_pass", 1, True), ("1_per_pass_one_stream", 1, False), ("8_per_pass", acc, False)):
+        window(P, multi)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        reps = 3
+        reps = 4
         for _ in range(reps):
-            window(P)
+            window(P, multi)
         torch.cuda.synchronize()
-        out["frames_per_s"][f"{P}_per_pass"] = round(reps * acc / (time.perf_counter() - t0), 1)
+        out["frames_per_s"][name] = round(reps * acc / (time.perf_counter() - t0), 1)
+    out["streams_1_per_pass"] = nstreams
+    pool.shutdown()
+    del lanes
+
+    # the autograd-tape path of round 2 on the same frames (comparison + per-kernel-kind rates)
+    net = PoseNet(N, K)
+    net.load_state_dict(sd)
+    net.to(device).train()
+    flat = train_utils.FlatParams(net)
+    opt2 = train_utils.FlatAdam(flat, lr=1e-4)
+    crit = Loss(M, sym_list)
+    fds = []
+    for o in objs:
+        fd = {k: torch.from_numpy(v).to(device) for k, v in o.items()}
+        train_utils.with_host_index(fd["obj"], o["obj"])
+        fds.append(fd)
+
+    def tape_step(fs):
+        with train_ops.splitk_scope(device):
+            img = torch.stack([f["img"] for f in fs]); cloud = torch.stack([f["cloud"] for f in fs])
+            choose = torch.stack([f["choose"] for f in fs]); obj = torch.stack([f["obj"] for f in fs])
+            r, t, c, emb = net(img, cloud, choose, obj)
+            loss = 0
+            for b, f in enumerate(fs):
+                loss = loss + crit(r[b:b + 1], t[b:b + 1], c[b:b + 1], f["target"][None], f["model_points"][None], f["obj"], f["cloud"][None],
+                                   0.015, False)[0]
+            loss.backward()
+
+    def tape_window(P):
+        for i in range(0, acc, P):
+            tape_step(fds[i:i + P])
+        opt2.step(); flat.zero_grad()
+
+    tape = {}
+    for P in (1, acc):
+        tape_window(P)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            tape_window(P)
+        torch.cuda.synchronize()
+        tape[f"{P}_per_pass"] = round(2 * acc / (time.perf_counter() - t0), 1)
+    out["autograd_tape_frames_per_s"] = tape
     kinds, whole = {}, {}
     for P in (1, acc):
         train_ops.profile_begin()
-        window(P)
+        tape_window(P)
         prof = train_ops.profile_end()
         for kind, (ms, fl, n) in prof.items():
             kinds.setdefault(kind, {})[f"{P}_per_pass"] = {"ms_per_window": round(ms, 3), "launches": n, "tflops": round(fl / ms / 1e9, 2) if ms > 0 else 0.0,
                                                            "frac": round(fl / ms / 1e9 / FP32_PEAK_TFLOPS, 4) if ms > 0 else 0.0}
-        # the whole step against the matrix peak: FLOPs of the three conv kernel kinds / wall time of an optimizer window
+        # the whole NATIVE step against the matrix peak: FLOPs of the reference layer graph's conv forward / data gradient / weight
+        # gradient launches (what the tape path executes; the native step executes fewer: low-resolution up-convs, folded head
+        # layer 1, chosen-pixel up_3) / wall time of an optimizer window
         wall_s = acc / out["frames_per_s"][f"{P}_per_pass"]
         fl = sum(v[1] for v in prof.values())
-        whole[f"{P}_per_pass"] = {"conv_gflop_per_frame": round(fl / acc / 1e9, 1), "tflops_wall": round(fl / wall_s / 1e12, 2),
+        whole[f"{P}_per_pass"] = {"conv_gflop_per_frame_reference_graph": round(fl / acc / 1e9, 1), "tflops_wall": round(fl / wall_s / 1e12, 2),
                                   "frac_of_mfma_peak": round(fl / wall_s / 1e12 / FP32_PEAK_TFLOPS, 4)}
-    out["conv_kernels"] = kinds
+    out["autograd_tape_conv_kernels"] = kinds
     out["whole_step"] = whole
     return out
 

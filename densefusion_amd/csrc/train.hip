@@ -67,8 +67,19 @@ __global__ __launch_bounds__(TB) void act_bwd2d_kernel(float *__restrict__ g, in
   }
 }
 
-// dst[j] (+)= sum_i part[i * n + j], i ascending: one thread per output
+// dst[j] (+)= sum_i part[i * n + j]: one thread per output, i ascending (n > 1); for a single output (n == 1: the PReLU slope) one
+// workgroup, thread t adds part[t], part[t + 256], ... and the 256 sums meet in a fixed tree
 __global__ __launch_bounds__(TB) void sum_partials_kernel(const float *__restrict__ part, int count, long n, float *__restrict__ dst, int accumulate) {
+  if (n == 1) {
+    __shared__ float s_red[TB];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < count; i += TB) a += part[i];
+    s_red[threadIdx.x] = a;
+    __syncthreads();
+    for (int d = TB / 2; d >= 1; d >>= 1) { if ((int)threadIdx.x < d) s_red[threadIdx.x] += s_red[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) dst[0] = accumulate ? dst[0] + s_red[0] : s_red[0];
+    return;
+  }
   GRID_STRIDE(j, n) {
     float a = 0.f;
     for (int i = 0; i < count; ++i) a += part[(long)i * n + j];
@@ -188,37 +199,55 @@ __global__ __launch_bounds__(TB) void bilinear_fwd_kernel(const float *__restric
     *reinterpret_cast<f32x4 *>(y + pix * y_ld + c) = o;
   }
 }
-// adjoint as a gather: dx[b][q] = sum over the destination pixels that read q (rows then columns ascending) of weight * dy
+// adjoint as a gather: dx[b][q] = sum over the destination pixels that read q of weight * dy.  Workgroup = 32 channel vectors x 8 row
+// lanes: lane l takes the candidate destination rows lo + l, lo + l + 8, ... (columns ascending inside a row), the 8 partial sums
+// meet in LDS and are added in lane order -- a fixed order, and 8 load chains instead of one (the 1 x 1 pyramid stage gathers the
+// whole map into one pixel)
 __global__ __launch_bounds__(TB) void bilinear_bwd_kernel(const float *__restrict__ dy, int dy_ld, float *__restrict__ dx, int B, int H, int W, int C4,
                                                           int OH, int OW, int align) {
-  GRID_STRIDE(i, (long)B * H * W * C4) {
-    const int c = (int)(i % C4) * 4;
-    long r = i / C4;
+  __shared__ f32x4 s_p[8][32];
+  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int cgroups = (C4 + 31) / 32;
+  for (long job = blockIdx.x; job < (long)B * H * W * cgroups; job += gridDim.x) {
+    const int cg = (int)(job % cgroups);
+    long r = job / cgroups;
+    const long pix = r;
     const int qx = (int)(r % W); r /= W;
     const int qy = (int)(r % H);
     const int b = (int)(r / H);
+    const int c4 = cg * 32 + col;
     int ylo, yhi, xlo, xhi;
     bil_cands(qy, H, OH, align, ylo, yhi);
     bil_cands(qx, W, OW, align, xlo, xhi);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int oy = ylo; oy <= yhi; ++oy) {
-      int y0, y1;
-      float wy0, wy1;
-      bil_src(oy, H, OH, align, y0, y1, wy0, wy1);
-      const float wy = (y0 == qy ? wy0 : 0.f) + (y1 == qy ? wy1 : 0.f);
-      if (y0 != qy && y1 != qy) continue;
-      for (int ox = xlo; ox <= xhi; ++ox) {
-        int x0, x1;
-        float wx0, wx1;
-        bil_src(ox, W, OW, align, x0, x1, wx0, wx1);
-        if (x0 != qx && x1 != qx) continue;
-        const float wx = (x0 == qx ? wx0 : 0.f) + (x1 == qx ? wx1 : 0.f);
-        const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + ((long)(b * OH + oy) * OW + ox) * dy_ld + c);
+    if (c4 < C4)
+      for (int oy = ylo + rl; oy <= yhi; oy += 8) {
+        int y0, y1;
+        float wy0, wy1;
+        bil_src(oy, H, OH, align, y0, y1, wy0, wy1);
+        if (y0 != qy && y1 != qy) continue;
+        const float wy = (y0 == qy ? wy0 : 0.f) + (y1 == qy ? wy1 : 0.f);
+        for (int ox = xlo; ox <= xhi; ++ox) {
+          int x0, x1;
+          float wx0, wx1;
+          bil_src(ox, W, OW, align, x0, x1, wx0, wx1);
+          if (x0 != qx && x1 != qx) continue;
+          const float wx = (x0 == qx ? wx0 : 0.f) + (x1 == qx ? wx1 : 0.f);
+          const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + ((long)(b * OH + oy) * OW + ox) * dy_ld + c4 * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += (wy * wx) * g[e];
+          for (int e = 0; e < 4; ++e) acc[e] += (wy * wx) * g[e];
+        }
       }
+    s_p[rl][col] = acc;
+    __syncthreads();
+    if (rl == 0 && c4 < C4) {
+#pragma unroll
+      for (int l = 1; l < 8; ++l)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += s_p[l][col][e];
+      reinterpret_cast<f32x4 *>(dx)[pix * C4 + c4] = acc;
     }
-    reinterpret_cast<f32x4 *>(dx)[i] = acc;
+    __syncthreads();
   }
 }
 
@@ -266,73 +295,102 @@ __global__ __launch_bounds__(TB) void upconv_gather_bwd_kernel(const float *__re
 
 // Adjoint of layers.hip up3_patch (the 3x3 patch of the bilinearly upsampled half-resolution map at every chosen pixel):
 // dU[b][qy][qx][c] = sum over points n (ascending) and taps (ascending) whose upsampled position interpolates from (qy, qx) of
-// weight * dpatch[b][n][tap][c].  A workgroup = one half-resolution row segment of one frame; the points' pixels are decoded
-// once into LDS with the range of half-resolution rows / columns their patch can touch, so a thread rejects most points on
-// two comparisons.
-constexpr int U3_PTS = 2048;
-__global__ __launch_bounds__(TB) void up3_patch_bwd_kernel(const float *__restrict__ dpatch, const int64_t *__restrict__ choose, float *__restrict__ dU,
-                                                           int h, int wd, int N, int Npad) {
-  __shared__ short s_py[U3_PTS], s_px[U3_PTS], s_rlo[U3_PTS], s_rhi[U3_PTS], s_clo[U3_PTS], s_chi[U3_PTS];
+// weight * dpatch[b][n][tap][c] -- a gather, so no atomics.  Three launches: decode every point's pixel and the range of
+// half-resolution rows / columns its patch can touch; per half-resolution row the ordered list of points that touch it; then a
+// thread per (pixel, 4 channels) walks its row's list (a few dozen points instead of all N).
+// tab[b][n] = {py | px << 16, rlo | rhi << 16, clo | chi << 16, 0}: the chosen pixel of point n and the range of half-resolution rows /
+// columns its 3 x 3 patch of upsampled positions interpolates from
+__global__ __launch_bounds__(TB) void up3_decode_kernel(const int64_t *__restrict__ choose, int4 *__restrict__ tab, int B, int h, int wd, int N) {
   const int OH = 2 * h, OW = 2 * wd, HW = OH * OW;
+  GRID_STRIDE(i, (long)B * N) {
+    long pix = choose[i];
+    pix = pix < 0 ? 0 : (pix >= HW ? HW - 1 : pix);
+    const int py = (int)(pix / OW), px = (int)(pix % OW);
+    int i0, i1, rlo, rhi, clo, chi;
+    float l0, l1;
+    bil_src(max(py - 1, 0), h, OH, 1, rlo, i1, l0, l1);
+    bil_src(min(py + 1, OH - 1), h, OH, 1, i0, rhi, l0, l1);
+    bil_src(max(px - 1, 0), wd, OW, 1, clo, i1, l0, l1);
+    bil_src(min(px + 1, OW - 1), wd, OW, 1, i0, chi, l0, l1);
+    tab[i] = make_int4(py | (px << 16), rlo | (rhi << 16), clo | (chi << 16), 0);
+  }
+}
+
+// rows[b][qy][...] = the points (ascending n) whose patch touches half-resolution row qy, cnt[b][qy] their number: a workgroup per row
+// scans the table once, 256 points per round, and compacts the hits in order (wave ballots + a scan over the 4 waves)
+__global__ __launch_bounds__(TB) void up3_rowlist_kernel(const int4 *__restrict__ tab, int *__restrict__ rows, int *__restrict__ cnt, int h, int N) {
+  __shared__ int s_w[4];
+  const int b = blockIdx.y, qy = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int *out = rows + ((size_t)b * h + qy) * N;
+  int base = 0;
+  for (int n0 = 0; n0 < N; n0 += TB) {
+    const int n = n0 + threadIdx.x;
+    bool hit = false;
+    if (n < N) {
+      const int4 e = tab[(size_t)b * N + n];
+      hit = qy >= (e.y & 0xffff) && qy <= (e.y >> 16);
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    int before = base;
+    for (int w2 = 0; w2 < wave; ++w2) before += s_w[w2];
+    if (hit) out[before + __popcll(m & ((1ull << lane) - 1ull))] = n;
+    base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cnt[b * h + qy] = base;
+}
+
+__global__ __launch_bounds__(TB) void up3_patch_bwd_kernel(const float *__restrict__ dpatch, const int4 *__restrict__ tab, const int *__restrict__ rows,
+                                                           const int *__restrict__ cnt, float *__restrict__ dU, int h, int wd, int N, int Npad) {
+  const int OH = 2 * h, OW = 2 * wd;
   const int b = blockIdx.z, qy = blockIdx.y;
   const int c4 = threadIdx.x & 15, qx = blockIdx.x * (TB / 16) + (threadIdx.x >> 4);
+  if (qx >= wd) return;
+  const int *list = rows + ((size_t)b * h + qy) * N;
+  const int count = cnt[b * h + qy];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int n0 = 0; n0 < N; n0 += U3_PTS) {
-    const int cnt = min(U3_PTS, N - n0);
-    __syncthreads();
-    for (int j = threadIdx.x; j < cnt; j += TB) {
-      long pix = choose[(size_t)b * N + n0 + j];
-      pix = pix < 0 ? 0 : (pix >= HW ? HW - 1 : pix);
-      const int py = (int)(pix / OW), px = (int)(pix % OW);
-      int i0, i1;
-      float l0, l1;
-      s_py[j] = (short)py; s_px[j] = (short)px;
-      bil_src(max(py - 1, 0), h, OH, 1, i0, i1, l0, l1); s_rlo[j] = (short)i0;
-      bil_src(min(py + 1, OH - 1), h, OH, 1, i0, i1, l0, l1); s_rhi[j] = (short)i1;
-      bil_src(max(px - 1, 0), wd, OW, 1, i0, i1, l0, l1); s_clo[j] = (short)i0;
-      bil_src(min(px + 1, OW - 1), wd, OW, 1, i0, i1, l0, l1); s_chi[j] = (short)i1;
-    }
-    __syncthreads();
-    if (qx < wd) {
-      for (int j = 0; j < cnt; ++j) {
-        if (qy < s_rlo[j] || qy > s_rhi[j] || qx < s_clo[j] || qx > s_chi[j]) continue;
-        const float *row = dpatch + ((size_t)b * Npad + n0 + j) * 576 + c4 * 4;
-        const int py = s_py[j], px = s_px[j];
+  for (int i = 0; i < count; ++i) {
+    const int j = list[i];
+    const int4 e4 = tab[(size_t)b * N + j];
+    if (qx < (e4.z & 0xffff) || qx > (e4.z >> 16)) continue;
+    const float *row = dpatch + ((size_t)b * Npad + j) * 576 + c4 * 4;
+    const int py = e4.x & 0xffff, px = e4.x >> 16;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          const int uy = py + dy - 1;
-          if ((unsigned)uy >= (unsigned)OH) continue;
-          int y0, y1;
-          float wy0, wy1;
-          bil_src(uy, h, OH, 1, y0, y1, wy0, wy1);
-          if (y0 != qy && y1 != qy) continue;
-          const float wy = (y0 == qy ? wy0 : 0.f) + (y1 == qy ? wy1 : 0.f);
+    for (int dy = 0; dy < 3; ++dy) {
+      const int uy = py + dy - 1;
+      if ((unsigned)uy >= (unsigned)OH) continue;
+      int y0, y1;
+      float wy0, wy1;
+      bil_src(uy, h, OH, 1, y0, y1, wy0, wy1);
+      if (y0 != qy && y1 != qy) continue;
+      const float wy = (y0 == qy ? wy0 : 0.f) + (y1 == qy ? wy1 : 0.f);
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const int ux = px + dx - 1;
-            if ((unsigned)ux >= (unsigned)OW) continue;
-            int x0, x1;
-            float wx0, wx1;
-            bil_src(ux, wd, OW, 1, x0, x1, wx0, wx1);
-            if (x0 != qx && x1 != qx) continue;
-            const float wx = (x0 == qx ? wx0 : 0.f) + (x1 == qx ? wx1 : 0.f);
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(row + (dy * 3 + dx) * 64);
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ux = px + dx - 1;
+        if ((unsigned)ux >= (unsigned)OW) continue;
+        int x0, x1;
+        float wx0, wx1;
+        bil_src(ux, wd, OW, 1, x0, x1, wx0, wx1);
+        if (x0 != qx && x1 != qx) continue;
+        const float wx = (x0 == qx ? wx0 : 0.f) + (x1 == qx ? wx1 : 0.f);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(row + (dy * 3 + dx) * 64);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += (wy * wx) * v[e];
-          }
-        }
+        for (int e = 0; e < 4; ++e) acc[e] += (wy * wx) * v[e];
       }
     }
   }
-  if (qx < wd) *reinterpret_cast<f32x4 *>(dU + (((size_t)b * h + qy) * wd + qx) * 64 + c4 * 4) = acc;
+  *reinterpret_cast<f32x4 *>(dU + (((size_t)b * h + qy) * wd + qx) * 64 + c4 * 4) = acc;
 }
 
-// Conv1d(3, 64, 1) on the cloud (lib/network.py:54): partial sums of dW [64][3], db [64] over a chunk of 256 points;
+// Conv1d(3, 64, 1) on the cloud (lib/network.py:54): partial sums of dW [64][3], db [64] over a chunk of 64 points;
 // g = the masked gradient of its output, a [B*Npad][64] view.  part[chunk][64][4] = (dW_x, dW_y, dW_z, db)
 __global__ __launch_bounds__(64) void cloud_conv1_bwd_kernel(const float *__restrict__ g, int g_ld, const float *__restrict__ cloud, int B, int N,
                                                              int Npad, float *__restrict__ part) {
-  const int chunks = (N + 255) / 256;
-  const int b = blockIdx.x / chunks, n0 = (blockIdx.x % chunks) * 256, n1 = min(N, n0 + 256);
+  const int chunks = (N + 63) / 64;
+  const int b = blockIdx.x / chunks, n0 = (blockIdx.x % chunks) * 64, n1 = min(N, n0 + 64);
   const int c = threadIdx.x;
   float ax = 0.f, ay = 0.f, az = 0.f, ab = 0.f;
   for (int n = n0; n < n1; ++n) {
@@ -372,7 +430,8 @@ __global__ __launch_bounds__(TB) void mask_bcast_kernel(const float *__restrict_
 }
 
 // s[b][c] = sum over the Npad rows of object b of g[.][c]: 32 columns x 8 row lanes per workgroup, rows in ascending order per lane
-__global__ __launch_bounds__(256) void colsum_obj_kernel(const float *__restrict__ g, int g_ld, float *__restrict__ s, int Npad, int C, long rows_total) {
+__global__ __launch_bounds__(256) void colsum_obj_kernel(const float *__restrict__ g, int g_ld, float *__restrict__ s, int Npad, int C, long rows_total,
+                                                         int accumulate = 0) {
   __shared__ float s_p[8][32];
   const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + col, b = blockIdx.y;
@@ -384,12 +443,13 @@ __global__ __launch_bounds__(256) void colsum_obj_kernel(const float *__restrict
   if (rl == 0 && c < C) {
 #pragma unroll
     for (int l = 1; l < 8; ++l) a += s_p[l][col];
-    s[(size_t)b * C + c] = a;
+    s[(size_t)b * C + c] = accumulate ? s[(size_t)b * C + c] + a : a;
   }
 }
 
 // global-feature half of head layer 1 (the 1024 broadcast channels folded into a per-object bias, engine.hip posenet_points):
 //   gbias[b][o] = Wg[o] . ap[b] + bias[o]   =>   dbias[o] += sum_b s[b][o],  dWg[o][j] += sum_b s[b][o] ap[b][j],  dap[b][j] = sum_o Wg[o][j] s[b][o]
+// (the last one is a [B x 1920] x [1920 x 1024] product: the GEMM kernel on the cached transpose of Wg)
 // with s[b][o] = the column sums over object b's points of the masked gradient of head layer 1's output
 __global__ __launch_bounds__(TB) void head1_global_wgrad_kernel(const float *__restrict__ s, const float *__restrict__ ap, float *__restrict__ dWg,
                                                                 float *__restrict__ dbias, int B, int O, int J4) {
@@ -409,17 +469,6 @@ __global__ __launch_bounds__(TB) void head1_global_wgrad_kernel(const float *__r
     if (j == 0) dbias[o] += sb;
   }
 }
-__global__ __launch_bounds__(TB) void head1_global_dgrad_kernel(const float *__restrict__ s, const float *__restrict__ Wg, float *__restrict__ dap, int B,
-                                                                int O, int J) {
-  GRID_STRIDE(i, (long)B * J) {
-    const int j = (int)(i % J);
-    const int b = (int)(i / J);
-    float a = 0.f;
-    for (int o = 0; o < O; ++o) a += Wg[(size_t)o * J + j] * s[(size_t)b * O + o];
-    dap[i] = a;
-  }
-}
-
 // last head layer for the frame's object only (layers.hip head_final): outputs j = 0..3 quaternion, 4..6 translation, 7 confidence
 // (sigmoid).  dz[b][n][j] = upstream gradient of the pre-sigmoid outputs; dh3 = dz . W rows; partial dW rows over chunks of 128 points.
 __global__ __launch_bounds__(TB) void head_final_bwd_kernel(const float *__restrict__ d_r, const float *__restrict__ d_t, const float *__restrict__ d_c,
@@ -612,6 +661,7 @@ struct PSpec {
 
 struct Trainer {
   int kind = 0, N = 0, K = 0, device = 0;
+  std::map<std::vector<int>, size_t> ws_cache;      // (B, H, W, M) -> workspace bytes (the sizing pass walks the whole step)
   std::vector<PSpec> spec;
   std::map<std::string, int> index;
   std::map<std::string, size_t> slot;        // internal name -> flat offset
@@ -712,6 +762,7 @@ void build_posenet(Trainer &t) {
   // head layer 1: towers stacked r, t, c; per-point block [1920][384], global-feature block [1920][1024], bias [1920]
   const size_t wpt = take(t, "head1.wpt", (size_t)1920 * 384), wg = take(t, "head1.wg", (size_t)1920 * 1024), b1 = take(t, "head1.bias", 1920);
   t.flips.push_back({wpt, 1920, 1, 384, 1, 1, 1});
+  t.flips.push_back({wg, 1920, 1, 1024, 1, 1, 1});
   const size_t w2 = take(t, "head2.w", (size_t)3 * 256 * 640), b2 = take(t, "head2.bias", 768);
   t.flips.push_back({w2, 256, 1, 640, 1, 1, 3});
   const size_t w3 = take(t, "head3.w", (size_t)3 * 128 * 256), b3 = take(t, "head3.bias", 384);
@@ -850,7 +901,7 @@ ConvParams base_params(const Act *x, int cin, const float *w, const float *bias,
 void launch_act_bwd(Step &s, Act *y, int act, const float *slope, float *dslope) {
   const long rows = y->rows();
   const int C4 = y->C / 4;
-  const unsigned blocks = act == 2 ? nblk(rows * C4, 1024) : nblk(rows * C4);
+  const unsigned blocks = act == 2 ? nblk(rows * C4, 512) : nblk(rows * C4);
   float *part = act == 2 ? s.f(blocks) : nullptr;
   if (!s.live()) return;
   hipLaunchKernelGGL(act_bwd2d_kernel, dim3(blocks), dim3(TB), 0, s.st, y->g.d, y->g.ld, y->v.d, y->v.ld, rows, C4, act, slope, part);
@@ -1005,7 +1056,7 @@ Act *upconv(Step &s, Act *x, const std::string &base, int cin, int cout) {
       float *part = s.f((size_t)nb * cout);
       if (s.live()) {
         hipLaunchKernelGGL(colsum_obj_kernel, dim3((cout + 31) / 32, nb), dim3(256), 0, s.st, o->g.d, o->g.ld, part, 256, cout, rows);
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(nblk(cout)), dim3(TB), 0, s.st, part, nb, (long)cout, s.gr(base + "conv.1.bias"), 1);
+        hipLaunchKernelGGL(colsum_obj_kernel, dim3((cout + 31) / 32, 1), dim3(256), 0, s.st, part, cout, s.gr(base + "conv.1.bias"), nb, cout, (long)nb, 1);
       }
     }
     s.grad_of(y);
@@ -1071,7 +1122,7 @@ void posenet_step(Step &s, const PoseNetIO &io) {
       Step &s = *sp;
       s.grad_of(z);
       if (s.live())
-        hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(nblk((long)B * sz * sz * 128)), dim3(TB), 0, s.st, cat->g.d + 512 * i, cat->g.ld, z->g.d, B, sz, sz, 128, h, w, 0);
+        hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)((long)B * sz * sz * 4)), dim3(TB), 0, s.st, cat->g.d + 512 * i, cat->g.ld, z->g.d, B, sz, sz, 128, h, w, 0);
     });
   }
   // the concat's gradient buffer is one allocation; layer4's output gradient is its last 512 channels
@@ -1093,9 +1144,15 @@ void posenet_step(Step &s, const PoseNetIO &io) {
   s.tape.push_back([=]() {
     Step &s = *sp;
     s.grad_of(u2);
-    if (s.live())
-      hipLaunchKernelGGL(up3_patch_bwd_kernel, dim3((u2->W + TB / 16 - 1) / (TB / 16), u2->H, B), dim3(TB), 0, s.st, patch->g.d, io.choose, u2->g.d, u2->H, u2->W,
-                         N, Npad);
+    int4 *tab = reinterpret_cast<int4 *>(s.bytes((size_t)B * N * sizeof(int4)));
+    int *rowlist = reinterpret_cast<int *>(s.bytes((size_t)B * u2->H * N * sizeof(int)));
+    int *rowcnt = reinterpret_cast<int *>(s.bytes((size_t)B * u2->H * sizeof(int)));
+    if (s.live()) {
+      hipLaunchKernelGGL(up3_decode_kernel, dim3(nblk((long)B * N)), dim3(TB), 0, s.st, io.choose, tab, B, u2->H, u2->W, N);
+      hipLaunchKernelGGL(up3_rowlist_kernel, dim3(u2->H, B), dim3(TB), 0, s.st, tab, rowlist, rowcnt, u2->H, N);
+      hipLaunchKernelGGL(up3_patch_bwd_kernel, dim3((u2->W + TB / 16 - 1) / (TB / 16), u2->H, B), dim3(TB), 0, s.st, patch->g.d, tab, rowlist, rowcnt, u2->g.d,
+                         u2->H, u2->W, N, Npad);
+    }
   });
   Act *z3 = conv(s, patch, 576, ConvW{C + "up_3.conv.1.weight", 0, C + "up_3.conv.1.bias", 0, C + "up_3.conv.2.weight"}, 64, 1, 1, 0, 1, ACT_PRELU);
   Act *emb_pm = s.act(rows, 1, 1, 32);
@@ -1135,7 +1192,7 @@ void posenet_step(Step &s, const PoseNetIO &io) {
     Step &s = *sp;
     Act m = *x1;
     launch_act_bwd(s, &m, ACT_RELU, nullptr, nullptr);
-    const int chunks = (N + 255) / 256;
+    const int chunks = (N + 63) / 64;
     float *part = s.f((size_t)B * chunks * 64 * 4);
     if (s.live()) {
       hipLaunchKernelGGL(cloud_conv1_bwd_kernel, dim3(B * chunks), dim3(64), 0, s.st, x1->g.d, 384, io.cloud, B, N, Npad, part);
@@ -1193,7 +1250,14 @@ void posenet_step(Step &s, const PoseNetIO &io) {
     if (s.live()) {
       hipLaunchKernelGGL(colsum_obj_kernel, dim3(1920 / 32, B), dim3(256), 0, s.st, h1->g.d, 1920, s1, Npad, 1920, (long)rows);
       hipLaunchKernelGGL(head1_global_wgrad_kernel, dim3(nblk((long)1920 * 256)), dim3(TB), 0, s.st, s1, apx, s.gr("head1.wg"), s.gr("head1.bias"), B, 1920, 256);
-      hipLaunchKernelGGL(head1_global_dgrad_kernel, dim3(nblk((long)B * 1024)), dim3(TB), 0, s.st, s1, s.p("head1.wg"), dap, B, 1920, 1024);
+    }
+    {
+      ConvParams q;
+      q.in = s1; q.B = B; q.Cin = 1920; q.in_ld = 1920;
+      q.wgt = s.pf("head1.wg");
+      q.out = dap; q.Cout = 1024; q.out_ld = 1024;
+      q.splitk_ws = s.splitk; q.splitk_ws_bytes = s.splitk_bytes;
+      if (s.live()) s.fail(launch_conv(q, s.st));
     }
   });
   Act *h2 = s.act(rows, 1, 1, 768), *h3 = s.act(rows, 1, 1, 384);
@@ -1291,7 +1355,7 @@ void refiner_step(Step &s, const RefinerIO &io) {
     Step &s = *sp;
     Act m = *x1;
     launch_act_bwd(s, &m, ACT_RELU, nullptr, nullptr);
-    const int chunks = (N + 255) / 256;
+    const int chunks = (N + 63) / 64;
     float *part = s.f((size_t)B * chunks * 64 * 4);
     if (s.live()) {
       hipLaunchKernelGGL(cloud_conv1_bwd_kernel, dim3(B * chunks), dim3(64), 0, s.st, x1->g.d, 384, io.points, B, N, Npad, part);
@@ -1459,10 +1523,16 @@ extern "C" int df_trainer_unpack_param(const df_trainer *h, const char *key, con
 
 extern "C" size_t df_posenet_train_workspace_bytes(const df_trainer *h, int B, int H, int W, int M) {
   if (!h || as_trainer(h)->kind != 0 || B <= 0 || H < 8 || W < 8 || M <= 0) return 0;
-  Step s{const_cast<Trainer *>(as_trainer(h)), nullptr, true, nullptr};
+  Trainer &t = *const_cast<Trainer *>(as_trainer(h));
+  const std::vector<int> key{B, H, W, M};
+  auto it = t.ws_cache.find(key);
+  if (it != t.ws_cache.end()) return it->second;
+  Step s{&t, nullptr, true, nullptr};
   PoseNetIO io{};
   io.B = B; io.H = H; io.W = W; io.M = M; io.dropout = 1;
   posenet_step(s, io);
+  if (t.ws_cache.size() > 4096) t.ws_cache.clear();
+  t.ws_cache[key] = s.peak;
   return s.peak;
 }
 
@@ -1490,10 +1560,15 @@ extern "C" int df_posenet_train_step(df_trainer *h, const float *flat_param, flo
 
 extern "C" size_t df_refiner_train_workspace_bytes(const df_trainer *h, int B, int M) {
   if (!h || as_trainer(h)->kind != 1 || B <= 0 || M <= 0) return 0;
-  Step s{const_cast<Trainer *>(as_trainer(h)), nullptr, true, nullptr};
+  Trainer &t = *const_cast<Trainer *>(as_trainer(h));
+  const std::vector<int> key{B, M};
+  auto it = t.ws_cache.find(key);
+  if (it != t.ws_cache.end()) return it->second;
+  Step s{&t, nullptr, true, nullptr};
   RefinerIO io{};
   io.B = B; io.M = M;
   refiner_step(s, io);
+  t.ws_cache[key] = s.peak;
   return s.peak;
 }
 

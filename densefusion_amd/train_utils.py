@@ -103,3 +103,62 @@ def host_index(idx):
     if h is not None:
         return int(h[0])
     return int(idx.reshape(-1)[0].item())
+
+
+class Prefetcher:
+    """Bounded look-ahead over ``dataset[i] for i in order`` (the job of the reference's 10-worker DataLoader, tools/train.py:106):
+    `workers` threads fetch frames, pin the host tensors and upload them on a copy stream, at most `depth` frames ahead of the
+    consumer; iteration yields the frames IN ORDER as tuples of device tensors whose upload the consumer's stream has been made
+    to wait for.  Items that are not tuples of tensors (a loader's sentinel) and tensors that already live on the device pass
+    through.  ``workers = 0``: fetch synchronously in the caller's thread (same results)."""
+
+    def __init__(self, dataset, order, device, workers=4, depth=None):
+        self.dataset, self.order, self.device = dataset, [int(i) for i in order], torch.device(device)
+        self.workers = max(0, int(workers))
+        self.depth = int(depth) if depth else max(2, 2 * self.workers)
+        self.copy_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+
+    def _fetch(self, i):
+        item = self.dataset[i]
+        if self.copy_stream is None or not isinstance(item, (tuple, list)):
+            return item, None
+        with torch.cuda.stream(self.copy_stream):
+            out = []
+            for t in item:
+                if torch.is_tensor(t) and not t.is_cuda:
+                    d = t.pin_memory().to(self.device, non_blocking=True)
+                    if not t.is_floating_point() and t.numel() <= 16:
+                        d._host = t.reshape(-1).tolist()       # small index tensors keep their host values (with_host_index)
+                    t = d
+                out.append(t)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        return tuple(out), ev
+
+    def __len__(self):
+        return len(self.order)
+
+    def __iter__(self):
+        if self.workers == 0:
+            for i in self.order:
+                item, ev = self._fetch(i)
+                if ev is not None:
+                    torch.cuda.current_stream(self.device).wait_event(ev)
+                yield item
+            return
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="df-prefetch") as pool:
+            pending, it = deque(), iter(self.order)
+            for i in it:
+                pending.append(pool.submit(self._fetch, i))
+                if len(pending) >= self.depth:
+                    break
+            while pending:
+                item, ev = pending.popleft().result()
+                nxt = next(it, None)
+                if nxt is not None:
+                    pending.append(pool.submit(self._fetch, nxt))
+                if ev is not None:
+                    torch.cuda.current_stream(self.device).wait_event(ev)
+                yield item

@@ -33,6 +33,7 @@ from densefusion_amd import synth, train_ops, train_utils  # noqa: E402
 from densefusion_amd.lib.loss import Loss  # noqa: E402
 from densefusion_amd.lib.loss_refiner import Loss_refine  # noqa: E402
 from densefusion_amd.lib.network import PoseNet, PoseRefineNet  # noqa: E402
+from densefusion_amd.native_train import NativeTrainer  # noqa: E402
 
 
 class SyntheticPoseDataset(torch.utils.data.Dataset):
@@ -69,7 +70,11 @@ def build_parser():
     ap.add_argument("--frames_per_pass", type=int, default=1,
                     help="frames of equal crop size, out of one accumulation window, that share a forward/backward pass (1 = the "
                          "reference's bs = 1 passes; the gradients of a window are the same either way)")
-    ap.add_argument("--workers", type=int, default=4)
+    ap.add_argument("--workers", type=int, default=4, help="prefetch threads: frames are fetched, pinned and uploaded on a copy stream "
+                                                         "ahead of the step (0 = fetch in the training loop)")
+    ap.add_argument("--autograd_tape", action="store_true",
+                    help="train through the per-layer autograd Functions of round 2 (lib/train_graph.py) instead of the native step "
+                         "(csrc/train.hip: forward + loss + backward of a pass in one library call); same gradients, several times slower")
     ap.add_argument("--lr", type=float, default=0.0001)
     ap.add_argument("--lr_rate", type=float, default=0.3)
     ap.add_argument("--w", type=float, default=0.015)
@@ -172,9 +177,24 @@ def main(argv=None):
     if not train_utils.replicas_in_sync([estimator, refiner]):
         raise RuntimeError("data-parallel ranks hold different weights after initialisation / resume")
 
+    # Native step (default): parameters and gradients of the network being trained live in the library's flat kernel-layout
+    # buffers (NativeTrainer); the nn.Modules keep serving the inference engine (frozen estimator of the refiner phase, test
+    # passes) and are refreshed from the flat buffer before they are used / saved.
+    native = {} if opt.autograd_tape else {"posenet": NativeTrainer("posenet", opt.num_points, opt.num_objects, dev),
+                                           "refiner": NativeTrainer("refiner", opt.num_points, opt.num_objects, dev)}
+    if native:
+        native["posenet"].load_state_dict(estimator.state_dict())
+        native["refiner"].load_state_dict(refiner.state_dict())
+
     def optimizer_for(module):
-        flat = train_utils.FlatParams(module)
+        flat = native["posenet" if module is estimator else "refiner"] if native else train_utils.FlatParams(module)
         return flat, train_utils.FlatAdam(flat, lr=opt.lr)
+
+    def sync_module(module):
+        """the nn.Module's tensors <- the flat buffer the native step trains (no-op on the autograd-tape path: same storage)"""
+        if native:
+            module.load_state_dict(native["posenet" if module is estimator else "refiner"].state_dict())
+        return module
 
     flat, optimizer = optimizer_for(refiner if opt.refine_start else estimator)
     opt.sym_list = dataset.get_sym_list()
@@ -198,12 +218,33 @@ def main(argv=None):
             return None
         f = lambda t: t.to(dev)[None]                # add the bs = 1 axis the DataLoader of the reference adds
         return (f(points), choose.to(dev).reshape(1, 1, -1), f(img), f(target), f(model_points),
-                train_utils.with_host_index(idx.to(dev).reshape(1, 1), idx))      # host copy kept: the losses branch on it without a read-back
+                train_utils.with_host_index(idx.to(dev).reshape(1, 1), getattr(idx, "_host", idx)))   # host copy kept: no read-back
 
     def run_pass(frames):
-        """Forward + loss + backward of `frames` (same crop size) in one pass; returns their distances."""
+        """Forward + loss + backward of `frames` (same crop size) in one pass; returns their distances (a device tensor [len(frames)]:
+        nothing is read back inside the accumulation window)."""
+        if native:
+            return _run_pass_native(frames)
         with train_ops.splitk_scope(dev):                # the small-map convolutions split their reductions (one registration per pass)
-            return _run_pass(frames)
+            return torch.tensor(_run_pass(frames), device=dev)
+
+    def _run_pass_native(frames):
+        points, choose, img, target, model_points = (torch.cat([f[k] for f in frames]) for k in (0, 1, 2, 3, 4))
+        idx = torch.cat([f[5] for f in frames])
+        sym = [train_utils.host_index(f[5]) in opt.sym_list for f in frames]
+        if not opt.refine_start:
+            return native["posenet"].step_posenet(img, points, choose, idx, target, model_points, sym, opt.w, dropout=True)["dis"]
+        with torch.no_grad():                            # the frozen estimator of the refiner phase: the fused inference engine
+            pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx)
+            new_points, new_target = [], []
+            for b, f in enumerate(frames):
+                _, _, npt, ntg = criterion(pred_r[b:b + 1], pred_t[b:b + 1], pred_c[b:b + 1], f[3], f[4], f[5], f[0], opt.w, True)
+                new_points.append(npt); new_target.append(ntg)
+            new_points, new_target = torch.cat(new_points), torch.cat(new_target)
+        for _ in range(opt.iteration):
+            out = native["refiner"].step_refiner(new_points, emb, idx, new_target, model_points, sym)
+            new_points, new_target = out["new_points"], out["new_target"]
+        return out["dis"]
 
     def _run_pass(frames):
         points, choose, img = (torch.cat([f[k] for f in frames]) for k in (0, 1, 2))
@@ -250,10 +291,14 @@ def main(argv=None):
         # sentinels (LineMOD) count toward the window like any frame: they add no gradient but never skip a collective.
         perm = np.random.RandomState(opt.seed + epoch).permutation(len(dataset))
         steps = len(dataset) // (world * opt.batch_size)
+        if steps == 0:
+            log.warning("epoch %d: %d training frames are fewer than ranks x batch_size = %d: no optimizer step this epoch", epoch, len(dataset),
+                        world * opt.batch_size)
         order = perm[:steps * world * opt.batch_size][rank::world]
         window, slots = [], 0
-        for i in order:
-            data = to_dev(dataset[int(i)])
+        window_dis = torch.zeros((), device=dev)
+        for item in train_utils.Prefetcher(dataset, order, dev, workers=opt.workers):
+            data = to_dev(item)
             slots += 1
             if data is not None:
                 window.append(data)
@@ -267,8 +312,7 @@ def main(argv=None):
                 by_size.setdefault(tuple(f[2].shape[-2:]), []).append(f)
             for group in by_size.values():
                 for g0 in range(0, len(group), max(1, opt.frames_per_pass)):
-                    for d in run_pass(group[g0:g0 + max(1, opt.frames_per_pass)]):
-                        train_dis_avg += d
+                    window_dis = window_dis + run_pass(group[g0:g0 + max(1, opt.frames_per_pass)]).sum()
             window = []
             prev = train_count
             train_count += opt.batch_size
@@ -276,22 +320,25 @@ def main(argv=None):
             n = allreduce(flat)                                   # the one collective of the training path
             optimizer.step(grad_scale=1.0 / n)
             flat.zero_grad()
+            train_dis_avg = float(window_dis)             # the window's one read-back (the log line below needs the number)
+            window_dis = torch.zeros((), device=dev)
             log.info("Train time %s Epoch %d Batch %d Frame %d Avg_dis:%f", time.strftime("%Hh %Mm %Ss", time.gmtime(time.time() - st_time)),
                      epoch, train_count // opt.batch_size, train_count, train_dis_avg / opt.batch_size)
             train_dis_avg = 0.0
             if train_count // 1000 != prev // 1000 and rank == 0:
                 if opt.refine_start:
-                    torch.save(refiner.state_dict(), "{0}/pose_refine_model_current.pth".format(opt.outf))
+                    torch.save(sync_module(refiner).state_dict(), "{0}/pose_refine_model_current.pth".format(opt.outf))
                 else:
-                    torch.save(estimator.state_dict(), "{0}/pose_model_current.pth".format(opt.outf))
+                    torch.save(sync_module(estimator).state_dict(), "{0}/pose_model_current.pth".format(opt.outf))
         log.info(">>>>>>>>----------epoch %d train finish---------<<<<<<<<", epoch)
 
         # per-epoch test pass (tools/train.py:181-209): the fused inference engine, no gradients
+        sync_module(refiner if opt.refine_start else estimator)
         estimator.eval(); refiner.eval()
         test_dis, test_count = 0.0, 0
         with torch.no_grad():
-            for j in range(rank, len(test_dataset), world):
-                data = to_dev(test_dataset[j])
+            for item in train_utils.Prefetcher(test_dataset, range(rank, len(test_dataset), world), dev, workers=opt.workers):
+                data = to_dev(item)
                 if data is None:
                     continue
                 points, choose, img, target, model_points, idx = data

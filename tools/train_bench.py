@@ -1,60 +1,44 @@
-"""Dev tool: training-step throughput (frames/s) on synthetic YCB-shaped frames (BASELINE configs[3] per GPU:
-K=21, N=1000, M=500, 8 frames accumulated per optimizer step, 5/21 objects symmetric).
-usage: train_bench.py [frames_per_pass]   -- 1 (default) = the reference's bs = 1 passes; P > 1 = P same-size frames per
-differentiable pass (same gradients, larger GEMMs)."""
+"""Dev tool: training-step throughput (frames/s) of the NATIVE step on synthetic YCB-shaped frames (BASELINE configs[3] per GPU:
+K=21, N=1000, M=500, 8 frames accumulated per optimizer step, half of the frames symmetric), crop sizes cycled over the bench's seven.
+usage: train_bench.py [frames_per_pass] [reps]   -- 1 (default) = the reference's bs = 1 passes; P > 1 = P same-size frames per call."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from densefusion_amd import synth, train_ops, train_utils
-from densefusion_amd.lib.loss import Loss
-from densefusion_amd.lib.network import PoseNet
+from densefusion_amd import synth, train_utils
+from densefusion_amd.native_train import NativeTrainer
 
 def main():
     K, N, M, acc = 21, 1000, 500, 8
     dev = torch.device("cuda")
-    net = PoseNet(N, K)
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.posenet_spec(K), 13).items()})
-    net.to(dev).train()
-    flat = train_utils.FlatParams(net); opt = train_utils.FlatAdam(flat, lr=1e-4)
-    crit = Loss(M, [12, 15, 18, 19, 20])
-    crops = [(80, 80), (120, 120), (120, 160), (160, 160), (160, 200), (200, 240), (240, 320)]
     P = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-    groups = []                                               # each group: P frames of one crop size
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    tr = NativeTrainer("posenet", N, K, dev)
+    tr.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.posenet_spec(K), 13).items()})
+    opt = train_utils.FlatAdam(tr, lr=1e-4)
+    crops = [(160, 160)] if os.environ.get("DF_TB_ONE_SIZE") else [(80, 80), (120, 120), (120, 160), (160, 160), (160, 200), (200, 240), (240, 320)]
+    sym_list = [12, 15, 18, 19, 20]
+    groups = []
     for gi in range(16 // P if P > 1 else 16):
         H, W = crops[gi % len(crops)]
-        fr = []
+        objs = []
         for j in range(P):
             o = synth.make_object(500 + gi * P + j, H, W, N, K, M)
-            o["obj"][0] = [12, 3, 15, 7][(gi + j) % 4]          # half of the frames symmetric (KNN loss branch)
-            fd = {k: torch.from_numpy(v).to(dev) for k, v in o.items()}
-            train_utils.with_host_index(fd["obj"], o["obj"])
-            fr.append(fd)
-        groups.append(fr)
-    def step(fr):
-        with train_ops.splitk_scope(dev):
-            return _step(fr)
-
-    def _step(fr):
-        img = torch.stack([f["img"] for f in fr]); cloud = torch.stack([f["cloud"] for f in fr])
-        choose = torch.stack([f["choose"] for f in fr]); obj = torch.stack([f["obj"] for f in fr])
-        r, t, c, emb = net(img, cloud, choose, obj)
-        loss = 0
-        for b, f in enumerate(fr):
-            loss = loss + crit(r[b:b + 1], t[b:b + 1], c[b:b + 1], f["target"][None], f["model_points"][None], f["obj"], f["cloud"][None],
-                               0.015, False)[0]
-        loss.backward()
-        return loss
-    for fr in groups[:2]: step(fr)
-    opt.step(); flat.zero_grad(); torch.cuda.synchronize()
+            o["obj"][0] = [12, 3, 15, 7][(gi + j) % 4]
+            objs.append(o)
+        fr = [torch.stack([torch.from_numpy(o[k]) for o in objs]).to(dev) for k in ("img", "cloud", "choose", "obj", "target", "model_points")]
+        groups.append((fr, [int(o["obj"][0]) in sym_list for o in objs]))
+    for fr, sym in groups:
+        tr.step_posenet(*fr, sym, 0.015)
+    opt.step(); tr.zero_grad(); torch.cuda.synchronize()
     t0 = time.perf_counter(); n = 0
-    for rep in range(2):
-        for fr in groups:
-            step(fr); n += len(fr)
+    for rep in range(reps):
+        for fr, sym in groups:
+            tr.step_posenet(*fr, sym, 0.015); n += len(sym)
             if n % acc == 0:
-                train_utils.allreduce_gradients(flat); opt.step(); flat.zero_grad()
+                opt.step(grad_scale=1.0 / acc); tr.zero_grad()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"training: {n/dt:.1f} frames/s ({dt/n*1e3:.1f} ms per frame fwd+bwd, {P} frame(s) per pass, optimizer step every {acc} frames)")
+    print(f"training (native step): {n/dt:.1f} frames/s ({dt/n*1e3:.2f} ms per frame fwd+bwd, {P} frame(s) per pass, optimizer step every {acc} frames)")
 
 if __name__ == "__main__":
     main()
