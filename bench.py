@@ -375,9 +375,9 @@ def bench_train(device):
     """BASELINE configs[3] per GPU: YCB training step, K=21, N=1000, M=500 (PoseNet phase), symmetric KNN loss on half of the
     frames, 8 frames accumulated per optimizer step (tools/train.py:131-170).  The step is the NATIVE one (csrc/train.hip:
     forward + loss + backward of the frames of a pass in one library call, gradients accumulated in the flat kernel-layout
-    buffer, Adam on that buffer): frames/s with the reference's bs = 1 passes (one call per frame; eager, and with the frames of
-    a window on `streams` HIP streams, each accumulating into its own gradient buffer, summed in a fixed order before the
-    optimizer step) and with the 8 frames of a window sharing one pass.  `autograd_tape`: the round-2 path (every layer a
+    buffer, Adam on that buffer): frames/s with the reference's bs = 1 passes (one call per frame: on one stream, and with the
+    passes of a window on 4 lanes -- native_train.Lanes: own stream, host thread, workspace and gradient buffer each, gradients
+    summed in lane order before the optimizer step) and with the 8 frames of a window sharing one pass.  `autograd_tape`: the round-2 path (every layer a
     Python autograd Function) on the same frames, with its per-kernel-kind TFLOP/s from HIP events around the conv launches."""
     from densefusion_amd import train_ops, train_utils
     from densefusion_amd.lib.loss import Loss
@@ -396,40 +396,20 @@ def bench_train(device):
     tr = NativeTrainer("posenet", N, K, device)
     tr.load_state_dict(sd)
     opt = train_utils.FlatAdam(tr, lr=1e-4)
+    from densefusion_amd.native_train import Lanes
     nstreams = int(os.environ.get("DF_BENCH_TRAIN_STREAMS", "4"))
-    lanes = [NativeTrainer("posenet", N, K, device) for _ in range(nstreams - 1)]       # extra lanes: own workspace + gradient buffer
-    streams = [torch.cuda.Stream() for _ in range(nstreams)]
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=nstreams)
+    lanes = Lanes(tr, nstreams)                  # pass j of a window on lane j % n: own stream, host thread, workspace, gradient buffer
 
     def frames(sl):
         return [fr[k][sl] for k in ("img", "cloud", "choose", "obj", "target", "model_points")]
 
     def window(P, multi=False):
-        if P == 1 and multi:
-            main = torch.cuda.current_stream()
-
-            def lane_work(li):           # one host thread per lane: the library call releases the GIL, launches are issued in parallel
-                torch.cuda.set_device(device)
-                lane = tr if li == 0 else lanes[li - 1]
-                with torch.cuda.stream(streams[li]):
-                    if li:
-                        lane.data, lane.version = tr.data, tr.version            # every lane reads the same parameters
-                    for i in range(li, acc, nstreams):
-                        lane.step_posenet(*frames(slice(i, i + 1)), sym[i:i + 1], 0.015, dropout=True)
-
-            for st in streams:
-                st.wait_stream(main)
-            for fut in [pool.submit(lane_work, li) for li in range(nstreams)]:
-                fut.result()
-            for st in streams:
-                main.wait_stream(st)
-            for lane in lanes:                                                       # fixed order: lane 1, 2, ...
-                tr.grad.add_(lane.grad)
-                lane.grad.zero_()
+        jobs = [(lambda lane, i=i: lane.step_posenet(*frames(slice(i, i + P)), sym[i:i + P], 0.015, dropout=True)) for i in range(0, acc, P)]
+        if multi:
+            lanes.run(jobs)
         else:
-            for i in range(0, acc, P):
-                tr.step_posenet(*frames(slice(i, i + P)), sym[i:i + P], 0.015, dropout=True)
+            for f in jobs:
+                f(tr)
         train_utils.allreduce_gradients(tr); opt.step(grad_scale=1.0 / acc); tr.zero_grad()
 
     out = {"workload": f"YCB training step, K={K}, N={N}, M={M}, crop {H}x{W}, {acc} frames per optimizer step, fp32, native step (csrc/train.hip)",
@@ -443,8 +423,8 @@ def bench_train(device):
             window(P, multi)
         torch.cuda.synchronize()
         out["frames_per_s"][name] = round(reps * acc / (time.perf_counter() - t0), 1)
-    out["streams_1_per_pass"] = nstreams
-    pool.shutdown()
+    out["lanes_1_per_pass"] = nstreams
+    lanes.close()
     del lanes
 
     # the autograd-tape path of round 2 on the same frames (comparison + per-kernel-kind rates)

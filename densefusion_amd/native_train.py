@@ -43,6 +43,7 @@ class NativeTrainer:
         self.module = None                   # (FlatAdam looks for an nn.Module to invalidate; there is none)
         self._ws = None
         self._calls = 0
+        self._salt = 0                       # a lane's offset into the dropout seed sequence (Lanes)
         self.spec = []
         key, shape, ndim = ctypes.create_string_buffer(256), (ctypes.c_int64 * 4)(), ctypes.c_int()
         for i in range(L.df_trainer_num_params(self._h)):
@@ -136,7 +137,7 @@ class NativeTrainer:
             out.update(pred_r=torch.empty(B, N, 4, device=dev), pred_t=torch.empty(B, N, 3, device=dev), pred_c=torch.empty(B, N, 1, device=dev))
         self._calls += 1
         if seed is None:
-            seed = (int(torch.initial_seed() % 100003) * 7919 + self._calls) & 0x3FFFFFFF
+            seed = (int(torch.initial_seed() % 100003) * 7919 + self._calls + self._salt) & 0x3FFFFFFF
         P = lambda k: out[k].data_ptr() if k in out else None
         L = _lib.lib()
         with _lib.device_guard(dev):
@@ -171,3 +172,57 @@ class NativeTrainer:
                                          ws.numel(), _lib.current_stream())
         _lib.check(st, "refiner_train_step")
         return out
+
+
+class Lanes:
+    """Run the passes of one accumulation window on `n` concurrent lanes.
+
+    A bs = 1 pass of the reference (tools/train.py:146-163) is a chain of a few hundred launches on sub-chip grids: one pass at a
+    time leaves most of the 256 CUs idle and the host thread is busy for as long as the GPU.  The frames of a window are
+    independent until their gradients are summed, so pass j runs on lane j % n: every lane has its own HIP stream, host thread
+    (the library call releases the GIL), workspace and gradient buffer, and reads the SAME parameter buffer; after the window the
+    lanes' gradients are added into lane 0's in lane order.  The result depends on n (a different summation order) but not on
+    timing: a fixed n gives bit-identical windows run to run."""
+
+    def __init__(self, trainer: NativeTrainer, n):
+        from concurrent.futures import ThreadPoolExecutor
+        self.tr, self.n = trainer, max(1, int(n))
+        self.lanes = [trainer] + [NativeTrainer(trainer.kind, trainer.num_points, trainer.num_obj, trainer.device) for _ in range(self.n - 1)]
+        for li, lane in enumerate(self.lanes):
+            lane._salt = li * 1_000_003
+        self.streams = [torch.cuda.Stream(trainer.device) for _ in range(self.n)]
+        self.pool = ThreadPoolExecutor(max_workers=self.n, thread_name_prefix="df-lane") if self.n > 1 else None
+
+    def run(self, jobs):
+        """jobs: callables ``f(lane_trainer) -> result``; returns their results in job order."""
+        if self.n == 1 or len(jobs) <= 1:
+            return [f(self.tr) for f in jobs]
+        dev = self.tr.device
+        main = torch.cuda.current_stream(dev)
+        results = [None] * len(jobs)
+
+        def work(li):
+            torch.cuda.set_device(dev)
+            lane = self.lanes[li]
+            with torch.cuda.stream(self.streams[li]):
+                if li:
+                    lane.data, lane.version = self.tr.data, self.tr.version
+                for j in range(li, len(jobs), self.n):
+                    results[j] = jobs[j](lane)
+
+        used = min(self.n, len(jobs))
+        for st in self.streams[:used]:
+            st.wait_stream(main)
+        for fut in [self.pool.submit(work, li) for li in range(used)]:
+            fut.result()
+        for st in self.streams[:used]:
+            main.wait_stream(st)
+        for lane in self.lanes[1:used]:
+            self.tr.grad.add_(lane.grad)
+            lane.grad.zero_()
+        return results
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.shutdown()
+            self.pool = None

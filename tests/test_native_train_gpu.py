@@ -223,3 +223,33 @@ def test_native_step_at_the_ycb_training_shape_with_adam_and_a_hipgraph():
     tr.zero_grad()
     out2 = tr.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], sym, 0.015, dropout=False)
     assert float(out2["loss"].sum()) < float(out["loss"].sum())
+
+
+def test_lanes_give_the_single_lane_gradients_and_repeat_bit_for_bit():
+    """native_train.Lanes: the bs = 1 passes of a window on 3 concurrent lanes (streams + host threads + own gradient buffers)
+    == the same passes one after the other, up to the summation order; a fixed lane count repeats bit for bit."""
+    from densefusion_amd.native_train import Lanes
+    K, N, H, W, M, B = 3, 128, 40, 80, 60, 5
+    sd = synth.make_state_dict(synth.posenet_spec(K), 19)
+    objs = [synth.make_object(400 + i, H if i % 2 else 80, W, N, K, num_points_mesh=M) for i in range(B)]      # two crop sizes in one window
+    for i, o in enumerate(objs):
+        o["obj"][0] = i % K
+    fr = [_frames([o]) for o in objs]
+    sym = [int(o["obj"][0]) == 1 for o in objs]
+    tr = _trainer("posenet", N, K, sd)
+    job = lambda i: (lambda lane: lane.step_posenet(fr[i]["img"], fr[i]["cloud"], fr[i]["choose"], fr[i]["obj"], fr[i]["target"], fr[i]["model_points"],
+                                                   [sym[i]], 0.015, dropout=False)["dis"])
+    single = [job(i)(tr) for i in range(B)]
+    g1 = tr.grad.clone()
+    lanes = Lanes(tr, 3)
+    runs = []
+    for _ in range(2):
+        tr.zero_grad()
+        dis = lanes.run([job(i) for i in range(B)])
+        torch.cuda.synchronize()
+        runs.append(tr.grad.clone())
+        for a, b in zip(dis, single):
+            assert torch.equal(a, b)
+    lanes.close()
+    assert torch.equal(runs[0], runs[1])
+    _close(runs[0], g1, 5e-4, "lane-summed gradient")

@@ -72,6 +72,10 @@ def build_parser():
                          "reference's bs = 1 passes; the gradients of a window are the same either way)")
     ap.add_argument("--workers", type=int, default=4, help="prefetch threads: frames are fetched, pinned and uploaded on a copy stream "
                                                          "ahead of the step (0 = fetch in the training loop)")
+    ap.add_argument("--lanes", type=int, default=4,
+                    help="PoseNet phase, native step: passes of one accumulation window run on this many concurrent lanes (own HIP stream, "
+                         "host thread, workspace and gradient buffer each; gradients summed in lane order): bs = 1 passes fill a fraction "
+                         "of the chip, so independent frames overlap.  1 = one pass at a time")
     ap.add_argument("--autograd_tape", action="store_true",
                     help="train through the per-layer autograd Functions of round 2 (lib/train_graph.py) instead of the native step "
                          "(csrc/train.hip: forward + loss + backward of a pass in one library call); same gradients, several times slower")
@@ -186,6 +190,11 @@ def main(argv=None):
         native["posenet"].load_state_dict(estimator.state_dict())
         native["refiner"].load_state_dict(refiner.state_dict())
 
+    lanes = None
+    if native and opt.lanes > 1:
+        from densefusion_amd.native_train import Lanes
+        lanes = Lanes(native["posenet"], opt.lanes)
+
     def optimizer_for(module):
         flat = native["posenet" if module is estimator else "refiner"] if native else train_utils.FlatParams(module)
         return flat, train_utils.FlatAdam(flat, lr=opt.lr)
@@ -228,12 +237,12 @@ def main(argv=None):
         with train_ops.splitk_scope(dev):                # the small-map convolutions split their reductions (one registration per pass)
             return torch.tensor(_run_pass(frames), device=dev)
 
-    def _run_pass_native(frames):
+    def _run_pass_native(frames, lane=None):
         points, choose, img, target, model_points = (torch.cat([f[k] for f in frames]) for k in (0, 1, 2, 3, 4))
         idx = torch.cat([f[5] for f in frames])
         sym = [train_utils.host_index(f[5]) in opt.sym_list for f in frames]
         if not opt.refine_start:
-            return native["posenet"].step_posenet(img, points, choose, idx, target, model_points, sym, opt.w, dropout=True)["dis"]
+            return (lane or native["posenet"]).step_posenet(img, points, choose, idx, target, model_points, sym, opt.w, dropout=True)["dis"]
         with torch.no_grad():                            # the frozen estimator of the refiner phase: the fused inference engine
             pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx)
             new_points, new_target = [], []
@@ -310,9 +319,13 @@ def main(argv=None):
             by_size = {}
             for f in window:
                 by_size.setdefault(tuple(f[2].shape[-2:]), []).append(f)
-            for group in by_size.values():
-                for g0 in range(0, len(group), max(1, opt.frames_per_pass)):
-                    window_dis = window_dis + run_pass(group[g0:g0 + max(1, opt.frames_per_pass)]).sum()
+            passes = [group[g0:g0 + max(1, opt.frames_per_pass)] for group in by_size.values() for g0 in range(0, len(group), max(1, opt.frames_per_pass))]
+            if lanes is not None and not opt.refine_start:
+                for d in lanes.run([(lambda lane, fs=fs: _run_pass_native(fs, lane)) for fs in passes]):
+                    window_dis = window_dis + d.sum()
+            else:
+                for fs in passes:
+                    window_dis = window_dis + run_pass(fs).sum()
             window = []
             prev = train_count
             train_count += opt.batch_size
