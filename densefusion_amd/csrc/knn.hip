@@ -9,6 +9,8 @@
 // coordinate order as ssd = fma(t, t, ssd) starting from 0 -- what nvcc's default contraction makes of
 // `ssd += tmp*tmp` (.cu:83-84) -- and a candidate replaces the best only on strict '<', so the lowest
 // reference index wins ties (.cu:128,152).  Indices are written 1-based as int64 (.cu:122,141,165).
+#include <cstdlib>
+
 #include "common.h"
 #include "knn_core.h"
 
@@ -51,6 +53,144 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn1_dim3_kernel(const float *__res
 #pragma unroll
   for (int j = 0; j < QPL; ++j) {
     int q = q0 + j * KNN_BLOCK;
+    if (q < Q) ind[q] = (int64_t)bi[j] + 1;
+  }
+}
+
+// The same scan with the reference points read through the SCALAR cache instead of LDS (s_load_dwordx8 of eight x, eight y, eight z:
+// the planar [3][R] layout of the reference's API is exactly what a scalar load wants): no staging pass, no barrier, no LDS reads
+// in the loop -- the packed subtractions take the coordinates straight from SGPR pairs.  Same operations in the same order as
+// knn1_scan (bit-identical indices); the winning chunk is re-scanned from global memory (per-lane addresses).
+// SPLIT > 1 (one launch that would leave the chip a handful of long-running waves per SIMD: 500 x 500 000 is 3.8 waves per SIMD, the
+// 4-wave SIMDs set the time and nothing hides a wave's dependent chains): SPLIT waves share the same 64 x QPL queries, wave w scans
+// the chunks w, w + SPLIT, ...; the partial winners meet in LDS and are combined by smaller distance, then lower index --
+// the winner of the single ascending scan (as in knn1_dim3_rsplit_kernel).
+template <int QPL, int SPLIT>
+__global__ __launch_bounds__(KNN_BLOCK) void knn1_dim3_sgpr_kernel(const float *__restrict__ ref, int R, const float *__restrict__ query, int Q,
+                                                                   int64_t *__restrict__ ind) {
+  static_assert(QPL % 2 == 0, "queries are processed as packed pairs");
+  static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "waves per query group");
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int CH = 8, GROUPS = KNN_BLOCK / 64 / SPLIT, QPB = GROUPS * 64 * QPL;      // query groups / queries per workgroup
+  __shared__ float s_d[SPLIT > 1 ? KNN_BLOCK * QPL : 1];
+  __shared__ int s_i[SPLIT > 1 ? KNN_BLOCK * QPL : 1];
+  const int b = blockIdx.y;
+  ref += (size_t)b * 3 * R;
+  query += (size_t)b * 3 * Q;
+  ind += (size_t)b * Q;
+  const float *__restrict__ rx = ref, *__restrict__ ry = ref + R, *__restrict__ rz = ref + 2 * (size_t)R;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave / SPLIT, part = wave - grp * SPLIT;
+  const int q0 = blockIdx.x * QPB + grp * 64 + lane;
+  constexpr int QSTRIDE = GROUPS * 64;
+  float qx[QPL], qy[QPL], qz[QPL], best[QPL];
+  int bc[QPL], bi[QPL];
+  f32x2 qx2[QPL / 2], qy2[QPL / 2], qz2[QPL / 2];
+#pragma unroll
+  for (int j = 0; j < QPL; ++j) {
+    const int q = q0 + j * QSTRIDE, qc = q < Q ? q : Q - 1;
+    qx[j] = query[qc]; qy[j] = query[Q + qc]; qz[j] = query[2 * (size_t)Q + qc];
+    best[j] = __builtin_inff(); bc[j] = part; bi[j] = 0;
+  }
+#pragma unroll
+  for (int j = 0; j < QPL / 2; ++j) {
+    qx2[j] = f32x2{qx[2 * j], qx[2 * j + 1]};
+    qy2[j] = f32x2{qy[2 * j], qy[2 * j + 1]};
+    qz2[j] = f32x2{qz[2 * j], qz[2 * j + 1]};
+  }
+  const int nchunk = R / CH;
+  // chunk c + 1 is requested before chunk c is multiplied (scalar loads return out of order: the wait in front of a chunk's first
+  // use covers everything outstanding, so without the look-ahead every chunk would expose a scalar-cache round trip)
+  float px[CH], py[CH], pz[CH];
+  if (nchunk > part) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { px[i] = rx[part * CH + i]; py[i] = ry[part * CH + i]; pz[i] = rz[part * CH + i]; }
+  }
+  for (int c = part; c < nchunk; c += SPLIT) {
+    float nx[CH], ny[CH], nz[CH];
+    const int cn = c + SPLIT < nchunk ? c + SPLIT : c;      // (the last round re-reads its own chunk: no branch in the loop)
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {                 // uniform addresses, read-only data: scalar loads
+      nx[i] = rx[cn * CH + i]; ny[i] = ry[cn * CH + i]; nz[i] = rz[cn * CH + i];
+    }
+    __builtin_amdgcn_sched_barrier(0);             // the requests go out BEFORE this round's arithmetic, not in the middle of it
+#pragma unroll
+    for (int j = 0; j < QPL / 2; ++j) {
+      float m0 = __builtin_inff(), m1 = __builtin_inff();
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const f32x2 tx = f32x2{px[i], px[i]} - qx2[j];
+        const f32x2 ty = f32x2{py[i], py[i]} - qy2[j];
+        const f32x2 tz = f32x2{pz[i], pz[i]} - qz2[j];
+        f32x2 d = tx * tx;
+        d = __builtin_elementwise_fma(ty, ty, d);
+        d = __builtin_elementwise_fma(tz, tz, d);
+        m0 = __builtin_fminf(m0, d.x);
+        m1 = __builtin_fminf(m1, d.y);
+      }
+      const bool lt0 = m0 < best[2 * j], lt1 = m1 < best[2 * j + 1];
+      best[2 * j] = lt0 ? m0 : best[2 * j];
+      bc[2 * j] = lt0 ? c : bc[2 * j];
+      best[2 * j + 1] = lt1 ? m1 : best[2 * j + 1];
+      bc[2 * j + 1] = lt1 ? c : bc[2 * j + 1];
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { px[i] = nx[i]; py[i] = ny[i]; pz[i] = nz[i]; }
+  }
+#pragma unroll
+  for (int j = 0; j < QPL; ++j) {
+    float b2 = __builtin_inff();
+    int i2 = 0;
+    const int base = bc[j] * CH;
+    if (nchunk > part) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const float tx = rx[base + i] - qx[j], ty = ry[base + i] - qy[j], tz = rz[base + i] - qz[j];
+        float d = tx * tx;
+        d = __builtin_fmaf(ty, ty, d);
+        d = __builtin_fmaf(tz, tz, d);
+        const bool lt = d < b2;
+        b2 = lt ? d : b2;
+        i2 = lt ? i : i2;
+      }
+    }
+    bi[j] = b2 < __builtin_inff() ? base + i2 : (SPLIT > 1 ? 0x7fffffff : 0);
+    best[j] = b2;
+  }
+  for (int r = nchunk * CH; r < R && part == SPLIT - 1; ++r) {                         // R % CH tail: plain scan (by the last part)
+    const float x = rx[r], y = ry[r], z = rz[r];
+#pragma unroll
+    for (int j = 0; j < QPL; ++j) {
+      const float tx = x - qx[j], ty = y - qy[j], tz = z - qz[j];
+      float d = tx * tx;
+      d = __builtin_fmaf(ty, ty, d);
+      d = __builtin_fmaf(tz, tz, d);
+      const bool lt = d < best[j];
+      best[j] = lt ? d : best[j];
+      bi[j] = lt ? r : bi[j];
+    }
+  }
+  if constexpr (SPLIT > 1) {
+#pragma unroll
+    for (int j = 0; j < QPL; ++j) { s_d[(wave * QPL + j) * 64 + lane] = best[j]; s_i[(wave * QPL + j) * 64 + lane] = bi[j]; }
+    __syncthreads();
+    if (part != 0) return;
+#pragma unroll
+    for (int j = 0; j < QPL; ++j) {
+#pragma unroll
+      for (int w = 1; w < SPLIT; ++w) {
+        const float d = s_d[((wave + w) * QPL + j) * 64 + lane];
+        const int i = s_i[((wave + w) * QPL + j) * 64 + lane];
+        const bool take = d < best[j] || (d == best[j] && i < bi[j]);
+        best[j] = take ? d : best[j];
+        bi[j] = take ? i : bi[j];
+      }
+      if (bi[j] == 0x7fffffff) bi[j] = 0;        // all-NaN column: row 0, like the reference's seed (.cu:120-122)
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < QPL; ++j) {
+    const int q = q0 + j * QSTRIDE;
     if (q < Q) ind[q] = (int64_t)bi[j] + 1;
   }
 }
@@ -164,15 +304,25 @@ int launch_knn(const float *ref, const float *query, int64_t *idx, int batch, in
     constexpr int WAVES = 16;     // 1024 threads: 64 queries x 16 reference slices per workgroup
     dim3 grid(df::cdiv(Q, 64), batch);
     hipLaunchKernelGGL(knn1_dim3_rsplit_kernel<WAVES>, grid, dim3(WAVES * 64), (size_t)R * 16 + WAVES * 64 * 8, st, ref, R, query, Q, idx);
-  } else if (dim == 3 && k == 1 && (size_t)R * 16 <= 64 * 1024) {
-    // 4 queries per lane amortise the LDS broadcast reads best (8 per lane measured no faster) but need
-    // >= ~8 waves per SIMD-slot of work to fill the chip; smaller problems keep 2 per lane for more waves
-    if ((long)Q * batch >= 4L * 1000 * 1000) {
-      dim3 grid(df::cdiv(Q, KNN_BLOCK * 4), batch);
-      hipLaunchKernelGGL(knn1_dim3_kernel<4>, grid, dim3(KNN_BLOCK), (size_t)R * 16, st, ref, R, query, Q, idx);
+  } else if (dim == 3 && k == 1) {
+    // default: reference points through the scalar cache, 2 queries per lane (measured on 500 x 500 000 / 64 x 500 x 1 000 000:
+    // 41.8 us / 3.46 ms against 48.3 us / 3.86 ms for the LDS-staged kernel; 4 queries per lane 45.8 us / 3.53 ms).
+    // DF_KNN_VARIANT (dev switch, A/B runs): 2 = scalar cache, 4 per lane; 3 / 4 = LDS-staged, 4 / 2 per lane (R <= 4096)
+    static const int variant = getenv("DF_KNN_VARIANT") ? atoi(getenv("DF_KNN_VARIANT")) : 0;
+    const bool lds_ok = (size_t)R * 16 <= 64 * 1024;
+    if (variant == 3 && lds_ok) {
+      hipLaunchKernelGGL(knn1_dim3_kernel<4>, dim3(df::cdiv(Q, KNN_BLOCK * 4), batch), dim3(KNN_BLOCK), (size_t)R * 16, st, ref, R, query, Q, idx);
+    } else if (variant == 4 && lds_ok) {
+      hipLaunchKernelGGL(knn1_dim3_kernel<2>, dim3(df::cdiv(Q, KNN_BLOCK * 2), batch), dim3(KNN_BLOCK), (size_t)R * 16, st, ref, R, query, Q, idx);
+    } else if (variant == 2) {
+      hipLaunchKernelGGL((knn1_dim3_sgpr_kernel<4, 1>), dim3(df::cdiv(Q, KNN_BLOCK * 4), batch), dim3(KNN_BLOCK), 0, st, ref, R, query, Q, idx);
     } else {
-      dim3 grid(df::cdiv(Q, KNN_BLOCK * 2), batch);
-      hipLaunchKernelGGL(knn1_dim3_kernel<2>, grid, dim3(KNN_BLOCK), (size_t)R * 16, st, ref, R, query, Q, idx);
+      // waves the launch would give every SIMD with one wave per 128 queries; below ~2 rounds of 8 the references are split too
+      const double wps = (double)Q * batch / 128.0 / 1024.0;
+      const int split = variant == 5 ? 1 : variant == 6 ? 2 : variant == 7 ? 4 : (wps < 6.0 && R >= 64 ? (wps < 3.0 ? 4 : 2) : 1);
+      if (split == 4) hipLaunchKernelGGL((knn1_dim3_sgpr_kernel<2, 4>), dim3(df::cdiv(Q, 128), batch), dim3(KNN_BLOCK), 0, st, ref, R, query, Q, idx);
+      else if (split == 2) hipLaunchKernelGGL((knn1_dim3_sgpr_kernel<2, 2>), dim3(df::cdiv(Q, 256), batch), dim3(KNN_BLOCK), 0, st, ref, R, query, Q, idx);
+      else hipLaunchKernelGGL((knn1_dim3_sgpr_kernel<2, 1>), dim3(df::cdiv(Q, 512), batch), dim3(KNN_BLOCK), 0, st, ref, R, query, Q, idx);
     }
   } else {
     dim3 grid(df::cdiv(Q, KNN_BLOCK), batch);
