@@ -19,7 +19,8 @@ class ConvDesc(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_void_p) for n in ("in_", "wgt", "bias", "res", "prelu", "out")] +
                 [(n, ctypes.c_int32) for n in ("B", "H", "W", "Cin", "in_ld", "in_coff", "OH", "OW", "Cout", "out_ld",
                                                "out_coff", "res_ld", "res_coff", "KH", "KW", "stride", "pad", "dil",
-                                               "act")])
+                                               "act")] +
+                [("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_size_t)])
 
 
 # symbol -> (restype, argtypes); must list every function include/dfusion.h declares
@@ -64,7 +65,7 @@ SIGNATURES = {
     "df_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
     "df_preprocess_objects": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "df_conv2d_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp]),
-    "df_conv_splitk_scratch": (_i, [_vp, _sz]),
+    "df_conv_last_splitk": (_i, []),
     "df_conv3x3_winograd_scratch_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "df_conv3x3_winograd_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, ctypes.c_size_t, _vp]),
     "df_wino_route": (_i, [_i, _i, _i, _i, _i]),

@@ -46,6 +46,11 @@ struct Net {
   size_t ev_used = 0;
   // debug taps (df_net_debug_taps): copies of named intermediates of the last single-bucket forward, channels-last
   bool psp_dirty = false;               // a psp.* weight changed since the folded matrices were built
+  // parameter uploads are enqueued on the null stream WITHOUT host synchronisation (one staging buffer, no per-tensor malloc /
+  // free / sync); the next forward call waits for them once (check_ready)
+  bool upload_pending = false;
+  float *stage = nullptr;
+  size_t stage_cap = 0;
   bool taps_on = false;
   struct Tap { float *buf = nullptr; size_t cap = 0; int64_t shape[4] = {0, 0, 0, 0}; };
   std::map<std::string, Tap> taps;
@@ -189,9 +194,10 @@ static int load_param(Net &n, const std::string &key, const float *src, int64_t 
                      (long long)numel, (long long)pi.numel());
   if (!src) return set_error(DF_ERR_ARG, "load_param: null pointer for %s", key.c_str());
   hipSetDevice(n.device);
-  auto copy = [&](float *dst, const float *s, size_t cnt) { return hipMemcpy(dst, s, cnt * sizeof(float), hipMemcpyDefault); };
+  n.upload_pending = true;
+  auto copy = [&](float *dst, const float *s, size_t cnt) { return hipMemcpyAsync(dst, s, cnt * sizeof(float), hipMemcpyDefault, 0); };
   auto copy2d = [&](float *dst, size_t dld, const float *s, size_t sld, size_t width, size_t rows) {
-    return hipMemcpy2D(dst, dld * sizeof(float), s, sld * sizeof(float), width * sizeof(float), rows, hipMemcpyDefault);
+    return hipMemcpy2DAsync(dst, dld * sizeof(float), s, sld * sizeof(float), width * sizeof(float), rows, hipMemcpyDefault, 0);
   };
   hipError_t e = hipSuccess;
   if (pi.ndim == 4 && !ends_with(key, "classifier.0.weight")) {
@@ -201,13 +207,16 @@ static int load_param(Net &n, const std::string &key, const float *src, int64_t 
     if (!dst) return set_error(DF_ERR_LAUNCH, "load_param: hipMalloc failed");
     if (HW == 1 && Ipad == I) e = copy(dst, src, (size_t)numel);
     else {
-      // src may be a host pointer: stage through a device temp
-      float *tmp = nullptr;
-      if (hipMalloc(&tmp, numel * sizeof(float)) != hipSuccess) return set_error(DF_ERR_LAUNCH, "hipMalloc failed");
-      e = copy(tmp, src, (size_t)numel);
-      hipLaunchKernelGGL(pack_oihw_kernel, dim3(256), dim3(256), 0, 0, tmp, dst, O, I, HW, Ipad);
-      hipDeviceSynchronize();
-      hipFree(tmp);
+      // src may be a host pointer: stage through the net's device staging buffer (grown on demand; stream order keeps a tensor's
+      // pack kernel ahead of the next tensor's copy into the same buffer)
+      if (n.stage_cap < (size_t)numel) {
+        if (n.stage) { hipStreamSynchronize(0); hipFree(n.stage); }
+        n.stage = nullptr; n.stage_cap = 0;
+        if (hipMalloc(&n.stage, (size_t)numel * sizeof(float)) != hipSuccess) return set_error(DF_ERR_LAUNCH, "hipMalloc failed");
+        n.stage_cap = (size_t)numel;
+      }
+      e = copy(n.stage, src, (size_t)numel);
+      hipLaunchKernelGGL(pack_oihw_kernel, dim3(256), dim3(256), 0, 0, n.stage, dst, O, I, HW, Ipad);
     }
     if (e == hipSuccess && key.find("feats.layer") != std::string::npos && HW == 9 && I >= 128 && I % 4 == 0 && O % 4 == 0) {
       // stride-1 3x3 convs of layer2 .. layer4 may run in the Winograd domain (wino_route decides per map size): transformed copies
@@ -216,7 +225,6 @@ static int load_param(Net &n, const std::string &key, const float *src, int64_t 
       if (!U || !U4) return set_error(DF_ERR_LAUNCH, "load_param: hipMalloc failed");
       launch_wino_weight(dst, U, O, I, 0, 2);
       launch_wino_weight(dst, U4, O, I, 0, 4);
-      hipDeviceSynchronize();
     }
     if (e == hipSuccess && (key.find(".up_1.") != std::string::npos || key.find(".up_2.") != std::string::npos) && HW == 9) {
       // up_1 / up_2 run as low-resolution 1x1 products per tap: keep a tap-major copy [9][O][I] (up_3 runs as a plain
@@ -224,7 +232,6 @@ static int load_param(Net &n, const std::string &key, const float *src, int64_t 
       float *tm = dev_alloc(n, key + ".tm", (size_t)9 * O * I);
       if (!tm) return set_error(DF_ERR_LAUNCH, "load_param: hipMalloc failed");
       launch_tapmajor(dst, tm, O, I, 0);
-      hipDeviceSynchronize();
     }
   } else if (n.kind == 0 && key.rfind("conv1_", 0) == 0) {
     // head layer 1 of tower h: split [640][1408] into the per-point part (first 384 input channels =
@@ -279,17 +286,23 @@ static int load_param(Net &n, const std::string &key, const float *src, int64_t 
 
 // (re)build what is derived from several parameters: the PSP fold (bottleneck x stage weights, fp64 accumulation)
 static int ensure_derived(Net &n) {
-  if (!n.psp_dirty) return DF_OK;
+  if (!n.psp_dirty) {
+    if (n.upload_pending) {               // the uploads of df_net_load_param ran on the null stream: one wait per batch of loads
+      if (hipStreamSynchronize(0) != hipSuccess) return set_error(DF_ERR_LAUNCH, "parameter upload failed: %s", hipGetErrorString(hipGetLastError()));
+      n.upload_pending = false;
+    }
+    return DF_OK;
+  }
   const std::string P = CNN;
   float *wc = dev_alloc(n, "psp.fold.w", (size_t)4 * 1024 * 512), *wf = dev_alloc(n, "psp.fold.wfeat", (size_t)1024 * 512);
   if (!wc || !wf) return set_error(DF_ERR_LAUNCH, "psp fold: hipMalloc failed");
   const float *wb = n.buf[P + "psp.bottleneck.weight"];
-  hipMemcpy2D(wf, 512 * sizeof(float), wb + 2048, 2560 * sizeof(float), 512 * sizeof(float), 1024, hipMemcpyDeviceToDevice);
+  hipMemcpy2DAsync(wf, 512 * sizeof(float), wb + 2048, 2560 * sizeof(float), 512 * sizeof(float), 1024, hipMemcpyDeviceToDevice, 0);
   for (int st = 0; st < 4; ++st)
     hipLaunchKernelGGL(psp_fold_kernel, dim3(2, 1024, 1), dim3(256), 0, 0, wb, n.buf[P + "psp.stages." + std::to_string(st) + ".1.weight"], wc, st);
-  hipDeviceSynchronize();
-  if (check_launch("psp fold") != DF_OK) return DF_ERR_LAUNCH;
+  if (hipStreamSynchronize(0) != hipSuccess || check_launch("psp fold") != DF_OK) return DF_ERR_LAUNCH;
   n.psp_dirty = false;
+  n.upload_pending = false;
   return DF_OK;
 }
 
@@ -568,9 +581,11 @@ static float *cnn_forward(Ctx &c, const std::vector<Grp> &gs, Level &half_lv) {
     Level lo;
     for (int i = 0; i < nb; ++i) lo.push(gs[i].B, 2 * lx.h[i], 2 * lx.w[i]);
     for (int i = 0; i < nb; ++i)
-      if (c.live())
-        launch_upconv_gather(y + lx.off[i] * 9 * up_out[u], c.w(P + ups[u] + ".conv.1.bias"), c.w(P + ups[u] + ".conv.2.weight"),
-                             o + lo.off[i] * up_out[u], gs[i].B, lx.h[i], lx.w[i], up_out[u], c.st);
+      if (c.live()) {
+        const int rc = launch_upconv_gather(y + lx.off[i] * 9 * up_out[u], c.w(P + ups[u] + ".conv.1.bias"), c.w(P + ups[u] + ".conv.2.weight"),
+                                            o + lo.off[i] * up_out[u], gs[i].B, lx.h[i], lx.w[i], up_out[u], c.st);
+        if (rc != DF_OK) c.err = rc;
+      }
     c.off = keep;        // the tap products are dead once interpolated
     (void)mark;
     lx = lo;
@@ -775,6 +790,7 @@ extern "C" void df_net_destroy(df_net *h) {
   if (!h) return;
   Net *n = as_net(h);
   for (auto &kv : n->buf) hipFree(kv.second);
+  if (n->stage) hipFree(n->stage);
   for (auto &kv : n->taps) if (kv.second.buf) hipFree(kv.second.buf);
   for (auto e : n->ev) hipEventDestroy(e);
   delete n;
@@ -1012,14 +1028,8 @@ extern "C" int df_estimate_poses(df_net *pn, df_net *rf, int B, int H, int W, co
 
 static int conv_desc_to_params(const df_conv_desc *d, ConvParams &p, const char *what);
 
-// split-K scratch of the stand-alone convolution entry points (training path; the engine's forward never uses it)
-static float *g_splitk_ws = nullptr;
-static size_t g_splitk_bytes = 0;
-extern "C" int df_conv_splitk_scratch(void *ptr, size_t bytes) {
-  g_splitk_ws = static_cast<float *>(ptr);
-  g_splitk_bytes = ptr ? bytes : 0;
-  return DF_OK;
-}
+static thread_local int t_last_splitk = 1;
+extern "C" int df_conv_last_splitk(void) { return t_last_splitk; }
 
 extern "C" int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream) {
   if (!d) return set_error(DF_ERR_ARG, "conv2d_nhwc: null descriptor");
@@ -1033,8 +1043,8 @@ extern "C" int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream) {
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.act = d->act;
   if (p.OH != conv_out(p.H, p.KH, p.stride, p.pad, p.dil) || p.OW != conv_out(p.W, p.KW, p.stride, p.pad, p.dil))
     return set_error(DF_ERR_ARG, "conv2d_nhwc: OH/OW do not match the convolution geometry");
-  p.splitk_ws = g_splitk_ws; p.splitk_ws_bytes = g_splitk_bytes;
-  return launch_conv(p, to_stream(stream));
+  p.splitk_ws = static_cast<float *>(d->splitk_ws); p.splitk_ws_bytes = d->splitk_ws ? d->splitk_ws_bytes : 0;
+  return launch_conv(p, to_stream(stream), &t_last_splitk);
 }
 
 // 3x3 stride-1 pad=dil convolution through the Winograd F(2x2,3x3) / F(4x4,3x3) domain (wino.hip): weight transform, input
@@ -1138,8 +1148,8 @@ extern "C" int df_conv2d_dgrad_nhwc(const df_conv_desc *d, const float *dy, floa
   q.KH = f.KH; q.KW = f.KW; q.stride = 1; q.up = f.stride; q.dil = f.dil; q.pad = f.dil * (f.KH - 1) - f.pad;
   if (q.pad < 0) return set_error(DF_ERR_ARG, "conv2d_dgrad: padding larger than the kernel reach is not supported");
   if (accumulate) { q.res = dx; q.res_ld = f.in_ld; q.res_coff = f.in_coff; }
-  q.splitk_ws = g_splitk_ws; q.splitk_ws_bytes = g_splitk_bytes;
-  return launch_conv(q, st);
+  q.splitk_ws = static_cast<float *>(d->splitk_ws); q.splitk_ws_bytes = d->splitk_ws ? d->splitk_ws_bytes : 0;
+  return launch_conv(q, st, &t_last_splitk);
 }
 
 extern "C" size_t df_conv2d_wgrad_workspace_bytes(const df_conv_desc *d) {

@@ -34,7 +34,7 @@ struct ConvParams {
   int ngroup = 0;   // column tiles per L2-resident weight group (0 = one group); set by launch_conv
   long z_in_coff = 0, z_wgt = 0, z_bias = 0, z_out_coff = 0;
   // magic pairs for the kernels' divisions by OH*OW and OW (set by the launchers)
-  // split-K (training path only: opt-in through a registered scratch, df_conv_splitk_scratch): launches that would fill less than
+  // split-K (training path only: opt-in through a caller-provided scratch, df_conv_desc.splitk_ws): launches that would fill less than
   // half the chip cut their reduction into `splitk` ranges (blockIdx.z), partial sums go to the scratch and a fixed-order reduce
   // kernel adds them and applies bias / residual / activation (deterministic).  splitk is set by launch_conv.
   float *splitk_ws = nullptr;
@@ -55,7 +55,7 @@ int conv_colsum_rows(const ConvParams &p);
 double conv_flops(const ConvParams &p);
 // algorithmic HBM bytes (inputs, weights, outputs and residual touched once)
 double conv_bytes(const ConvParams &p);
-int launch_conv(const ConvParams &p, hipStream_t st);
+int launch_conv(const ConvParams &p, hipStream_t st, int *splitk_used = nullptr);     // splitk_used: the K ranges the launch was cut into
 
 // dW[n][(ky,kx,c)] += sum_m dY[m][n] * A[m][(ky,kx,c)]  (A = the im2col view of x of the forward conv `p`; p.out = dY)
 // dw / db (optional: column sums of dY) are overwritten.  The pixel range is split over workgroups; the partial tiles go to `ws`

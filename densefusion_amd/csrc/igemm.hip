@@ -1275,7 +1275,7 @@ double conv_flops(const ConvParams &p) {
   return 2.0 * p.B * p.OH * p.OW * (double)p.Cout * p.KH * p.KW * p.Cin * p.zcount;
 }
 
-int launch_conv(const ConvParams &p, hipStream_t st) {
+int launch_conv(const ConvParams &p, hipStream_t st, int *splitk_used) {
   if (!p.in || !p.wgt || (!p.out && !p.colsum)) return set_error(DF_ERR_ARG, "conv: null pointer");
   if (p.Cin % 4 || p.in_ld % 4 || p.in_coff % 4 || p.z_in_coff % 4 || p.z_wgt % 4)
     return set_error(DF_ERR_ARG, "conv: Cin/in_ld/in_coff must be multiples of 4 (16-B vector loads)");
@@ -1345,6 +1345,7 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
     if ((long)S * M * p.Cout >= (1L << 31)) S = 1;
     if (S < 1) S = 1;
   }
+  if (splitk_used) *splitk_used = S;
   if (S > 1) {
     pl.splitk = S;
     pl.out = p.splitk_ws; pl.out_ld = p.Cout; pl.out_coff = 0; pl.z_out_coff = M * p.Cout;

@@ -16,8 +16,8 @@ void launch_psp_pool(const float *in, int in_ld, int in_coff, float *out, int B,
 void launch_psp_prior_sum(const float *z, float *out, int B, int H, int W, int C, hipStream_t st);
 // PSPUpsample (x2 bilinear align_corners=True -> conv3x3 pad 1 -> PReLU, lib/pspnet.py:27-37) from the nine
 // low-resolution 1x1 products y [B][h][w][9*Cout] (tap-major): out [B][2h][2w][Cout].  See layers.hip.
-void launch_upconv_gather(const float *y, const float *bias, const float *prelu, float *out, int B, int h, int w, int Cout,
-                          hipStream_t st);
+int launch_upconv_gather(const float *y, const float *bias, const float *prelu, float *out, int B, int h, int w, int Cout,
+                         hipStream_t st);
 void launch_tapmajor(const float *src, float *dst, int O, int I, hipStream_t st);   // [O][9][I] -> [9][O][I]
 // up_3 only at the N chosen pixels (lib/network.py:98-102): per chosen pixel the 3x3 patch of the bilinearly upsampled
 // (align_corners) half-resolution map x [B][h][w][64], as GEMM rows patch [B*Npad][9*64] (zero rows for n >= N);

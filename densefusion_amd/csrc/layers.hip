@@ -222,46 +222,7 @@ __device__ inline Tap3 taps_for(int P, float scale, int in_size, int out_size) {
   return t;
 }
 
-__global__ __launch_bounds__(TPB) void upconv_gather_kernel(const float *__restrict__ y, const float *__restrict__ bias,
-                                                            const float *__restrict__ prelu, float *__restrict__ out, int B,
-                                                            int h, int w, int Cout) {
-  const int OH = 2 * h, OW = 2 * w, C4 = Cout / 4, ldy = 9 * Cout;
-  const float sh = OH > 1 ? (float)(h - 1) / (float)(OH - 1) : 0.f;
-  const float sw = OW > 1 ? (float)(w - 1) / (float)(OW - 1) : 0.f;
-  const float slope = prelu[0];
-  const long total = (long)B * OH * OW * C4;
-  for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
-    const int c = (int)(i % C4) * 4;
-    long r = i / C4;
-    const int px = (int)(r % OW); r /= OW;
-    const int py = (int)(r % OH);
-    const int b = (int)(r / OH);
-    const Tap3 ty = taps_for(py, sh, h, OH), tx = taps_for(px, sw, w, OW);
-    const float *yb = y + (size_t)b * h * w * ldy + c;
-    f32x4 acc = *reinterpret_cast<const f32x4 *>(bias + c);
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      if (!ty.ok[dy]) continue;
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        if (!tx.ok[dx]) continue;
-        const float *t = yb + (dy * 3 + dx) * Cout;
-        const f32x4 v00 = *reinterpret_cast<const f32x4 *>(t + (size_t)(ty.i0[dy] * w + tx.i0[dx]) * ldy);
-        const f32x4 v01 = *reinterpret_cast<const f32x4 *>(t + (size_t)(ty.i0[dy] * w + tx.i1[dx]) * ldy);
-        const f32x4 v10 = *reinterpret_cast<const f32x4 *>(t + (size_t)(ty.i1[dy] * w + tx.i0[dx]) * ldy);
-        const f32x4 v11 = *reinterpret_cast<const f32x4 *>(t + (size_t)(ty.i1[dy] * w + tx.i1[dx]) * ldy);
-        const f32x4 v = lerp4(v00, v01, v10, v11, ty.w0[dy], ty.w1[dy], tx.w0[dx], tx.w1[dx]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += v[e];
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = acc[e] > 0.f ? acc[e] : acc[e] * slope;
-    reinterpret_cast<f32x4 *>(out)[i] = acc;
-  }
-}
-
-// LDS-tiled form of the kernel above: a workgroup owns an 8 x 16 tile of output pixels and 16 output channels.  The
+// LDS-tiled: a workgroup owns an 8 x 16 tile of output pixels and 16 output channels.  The
 // low-resolution rows / columns its 3x3 taps interpolate from (<= 7 x 11 pixels) are staged in LDS once, all nine tap
 // blocks of the 16 channels (44 KB), so the 36 vector reads per output vector come from LDS and global traffic drops
 // from 36 to ~5.4 vector reads per output vector.  thread = (pixel of the tile, 4 channels).
@@ -631,18 +592,16 @@ void launch_final_logsoftmax(const float *z, const float *w, const float *bias, 
   const long jobs = (long)B * ((N + LSM_PTS - 1) / LSM_PTS);
   hipLaunchKernelGGL(final_lsm_kernel, dim3((unsigned)(jobs < 2048 ? (jobs < 1 ? 1 : jobs) : 2048)), dim3(TPB), 0, st, z, w, bias, emb, emb_pm, B, N, Npad);
 }
-void launch_upconv_gather(const float *y, const float *bias, const float *prelu, float *out, int B, int h, int w, int Cout,
-                          hipStream_t st) {
-  static const bool plain = getenv("DF_UPCONV_PLAIN") != nullptr;      // dev switch: the un-tiled kernel
+int launch_upconv_gather(const float *y, const float *bias, const float *prelu, float *out, int B, int h, int w, int Cout,
+                         hipStream_t st) {
+  // host-checked: the kernel's 24-bit offset multiplies, its 32-bit buffer offsets, the grid's z range
   const long gz = (long)B * (Cout / UG_CC);
-  if (!plain && Cout % UG_CC == 0 && gz <= 65535 && (long)w * 9 * Cout * 4 < (1L << 24) && h < (1 << 24) &&
-      (long)h * w * 9 * Cout * 4 < (1L << 32)) {
-    dim3 grid((2 * w + UG_TX - 1) / UG_TX, (2 * h + UG_TY - 1) / UG_TY, (unsigned)gz);
-    hipLaunchKernelGGL(upconv_gather_tiled_kernel, grid, dim3(512), 0, st, y, bias, prelu, out, B, h, w, Cout);
-    return;
-  }
-  hipLaunchKernelGGL(upconv_gather_kernel, dim3(blocks_for((long)B * 4 * h * w * (Cout / 4))), dim3(TPB), 0, st, y, bias, prelu,
-                     out, B, h, w, Cout);
+  if (Cout % UG_CC || gz > 65535 || (long)w * 9 * Cout * 4 >= (1L << 24) || h >= (1 << 24) || (long)h * w * 9 * Cout * 4 >= (1L << 32))
+    return set_error(DF_ERR_ARG, "upconv_gather: needs Cout %% 16 == 0, B * Cout / 16 <= 65535 and a low-resolution image under 4 GB (got B %d, %d x %d, Cout %d)",
+                     B, h, w, Cout);
+  dim3 grid((2 * w + UG_TX - 1) / UG_TX, (2 * h + UG_TY - 1) / UG_TY, (unsigned)gz);
+  hipLaunchKernelGGL(upconv_gather_tiled_kernel, grid, dim3(512), 0, st, y, bias, prelu, out, B, h, w, Cout);
+  return DF_OK;
 }
 void launch_tapmajor(const float *src, float *dst, int O, int I, hipStream_t st) {
   hipLaunchKernelGGL(tapmajor_kernel, dim3(blocks_for((long)O * 9 * I)), dim3(TPB), 0, st, src, dst, O, I);

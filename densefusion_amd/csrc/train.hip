@@ -1045,7 +1045,7 @@ Act *upconv(Step &s, Act *x, const std::string &base, int cin, int cout) {
   p.splitk_ws = s.splitk; p.splitk_ws_bytes = s.splitk_bytes;
   if (s.live()) s.fail(launch_conv(p, s.st));
   Act *o = s.act(B, 2 * h, 2 * w, cout);
-  if (s.live()) launch_upconv_gather(y->v.d, s.p(base + "conv.1.bias"), s.p(base + "conv.2.weight"), o->v.d, B, h, w, cout, s.st);
+  if (s.live()) s.fail(launch_upconv_gather(y->v.d, s.p(base + "conv.1.bias"), s.p(base + "conv.2.weight"), o->v.d, B, h, w, cout, s.st));
   Step *sp = &s;
   s.tape.push_back([=]() {
     Step &s = *sp;

@@ -74,19 +74,21 @@ class _EngineModule(nn.Module):
             self._handle_dev = device
             self._uploaded = {}
         synced = False
+        self._upload_keep = []       # converted temporaries of this batch of uploads: alive until the next forward has waited for the copies
         for key, p in self.named_parameters():
             if p.device != device:
                 raise RuntimeError(f"parameter {key} is on {p.device}, input on {device}: call .cuda() first")
             tag = (p.data_ptr(), p._version)
             if self._uploaded.get(key) != tag:
                 if not synced:
-                    # df_net_load_param copies with blocking calls outside torch's streams: an optimizer update still in
-                    # flight on the current stream must have landed before the parameters are read
+                    # df_net_load_param enqueues its copies on the null stream, outside torch's streams: an optimizer update
+                    # still in flight on the current stream must have landed before the parameters are read
                     torch.cuda.current_stream(device).synchronize()
                     synced = True
                 src = p.detach()
                 if src.dtype != torch.float32 or not src.is_contiguous():
                     src = src.float().contiguous()
+                    self._upload_keep.append(src)
                 _lib.check(L.df_net_load_param(self._handle, key.encode(), src.data_ptr(), src.numel()), f"load_param({key})")
                 self._uploaded[key] = tag
         return self._handle

@@ -2,10 +2,25 @@
 from __future__ import annotations
 
 import ctypes
+import threading
 
 import torch
 
 from . import _lib
+
+
+_TLS = threading.local()        # .splitk: the split-K scratch tensor of the enclosing train_ops.splitk_scope (per thread), or None
+
+
+def current_splitk():
+    return getattr(_TLS, "splitk", None)
+
+
+def _with_splitk(d):
+    buf = current_splitk()
+    if buf is not None:
+        d.splitk_ws, d.splitk_ws_bytes = buf.data_ptr(), buf.numel()
+    return d
 
 
 def conv2d_nhwc(x, w, bias=None, stride=1, pad=0, dil=1, act=0, res=None, prelu=None, out=None, out_coff=0,
@@ -21,7 +36,7 @@ def conv2d_nhwc(x, w, bias=None, stride=1, pad=0, dil=1, act=0, res=None, prelu=
     OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
     if out is None:
         out = torch.empty(B, OH, OW, Cout, device=x.device, dtype=torch.float32)
-    d = _lib.ConvDesc()
+    d = _with_splitk(_lib.ConvDesc())
     d.in_, d.wgt, d.out = _lib.dptr(x), _lib.dptr(w), _lib.dptr(out)
     d.bias = _lib.dptr(bias) if bias is not None else None
     d.res = _lib.dptr(res) if res is not None else None
@@ -38,7 +53,7 @@ def conv2d_nhwc(x, w, bias=None, stride=1, pad=0, dil=1, act=0, res=None, prelu=
 def _desc(x, w, out, stride, pad, dil, act=0, bias=None):
     B, H, W, in_ld = x.shape
     Cout, KH, KW, Cin = w.shape
-    d = _lib.ConvDesc()
+    d = _with_splitk(_lib.ConvDesc())
     d.in_, d.wgt, d.out = _lib.dptr(x), _lib.dptr(w), (_lib.dptr(out) if out is not None else None)
     d.bias = _lib.dptr(bias) if bias is not None else None
     d.B, d.H, d.W, d.Cin, d.in_ld, d.in_coff = B, H, W, Cin, in_ld, 0

@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import _lib
-from .ops import _desc, conv2d_nhwc, wgrad
+from .ops import _desc, _with_splitk, conv2d_nhwc, wgrad
 
 
 def _st():
@@ -62,30 +62,31 @@ _SPLITK = {}          # device index -> persistent scratch tensor
 
 
 class _splitk:
-    """Registers the split-K scratch (df_conv_splitk_scratch) for the launches inside the block: the convolutions of a training pass on
-    small maps (layer3 / layer4: a few hundred pixels, reductions of 2304 / 4608) otherwise launch far fewer tiles than the chip has CUs.
-    Deterministic (fixed-order reduce); off with DF_TRAIN_NO_SPLITK=1.  Re-entrant: only the outermost block talks to the library, so a
-    trainer that wraps a whole forward + backward pass in `splitk_scope` pays two calls per pass instead of two per convolution."""
-    _depth = 0
+    """Split-K scratch for the convolution launches inside the block: the convolutions of a training pass on small maps (layer3 /
+    layer4: a few hundred pixels, reductions of 2304 / 4608) otherwise launch far fewer tiles than the chip has CUs.  The scratch
+    travels in every launch's descriptor (``df_conv_desc.splitk_ws``): nothing is registered with the library, the scope is a
+    per-thread setting of this module (``ops.current_splitk``), nested scopes are no-ops and an exception inside leaves no state
+    behind.  Deterministic (fixed-order reduce); off with DF_TRAIN_NO_SPLITK=1."""
 
     def __init__(self, device):
         self.dev = device
+        self.outer = None
 
     def __enter__(self):
-        _splitk._depth += 1
-        if _splitk._depth > 1 or os.environ.get("DF_TRAIN_NO_SPLITK"):
+        from . import ops
+        self.outer = ops.current_splitk()
+        if self.outer is not None or os.environ.get("DF_TRAIN_NO_SPLITK"):
             return self
         key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         buf = _SPLITK.get(key)
         if buf is None:
             buf = _SPLITK[key] = torch.empty(64 << 20, dtype=torch.uint8, device=self.dev)
-        _ck(_lib.lib().df_conv_splitk_scratch(buf.data_ptr(), buf.numel()), "conv_splitk_scratch")
+        ops._TLS.splitk = buf
         return self
 
     def __exit__(self, *a):
-        _splitk._depth -= 1
-        if _splitk._depth == 0:
-            _lib.lib().df_conv_splitk_scratch(None, 0)
+        from . import ops
+        ops._TLS.splitk = self.outer
         return False
 
 
@@ -131,6 +132,7 @@ class ConvAct(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 scratch = torch.empty_like(w)
                 with _Timed("dgrad", _conv_flops(x, w, y)), _splitk(x.device):
+                    _with_splitk(d)
                     _ck(L.df_conv2d_dgrad_nhwc(ctypes.byref(d), g.data_ptr(), dx.data_ptr(), scratch.data_ptr(), 0, _st()), "conv2d_dgrad")
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                 dw = torch.empty_like(w)

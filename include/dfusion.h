@@ -68,7 +68,9 @@ df_net *df_refiner_create(int num_points, int num_obj);   /* PoseRefineNet(...),
 void df_net_destroy(df_net *net);
 int df_net_num_params(const df_net *net);                  /* 77 tensors for PoseNet, 24 for the refiner */
 int df_net_param_info(const df_net *net, int i, char *key_out, int key_cap, int64_t *shape4, int *ndim);
-/* ptr: `numel` fp32 values in the reference layout (device or host pointer) */
+/* ptr: `numel` fp32 values in the reference layout (device or host pointer).  The copy, the re-layout and the derived copies
+ * (Winograd-domain, tap-major) are ENQUEUED (null stream) without host synchronisation; the next forward call on this handle waits
+ * for the batch once.  A DEVICE source must stay allocated until then (a host source is consumed before the call returns). */
 int df_net_load_param(df_net *net, const char *key, const float *ptr, int64_t numel);
 
 /* Batched PoseNet.forward (lib/network.py:95-132), eval mode (Dropout2d = identity).
@@ -209,14 +211,17 @@ typedef struct df_conv_desc {
   int32_t OH, OW, Cout, out_ld, out_coff;
   int32_t res_ld, res_coff;
   int32_t KH, KW, stride, pad, dil, act;
+  /* optional split-K scratch (device, owned by the caller, NULL = never split): with it df_conv2d_nhwc and df_conv2d_dgrad_nhwc cut
+   * the reduction of launches that would fill less than half the chip (a few hundred pixels x a few thousand taps*channels: the
+   * layer3 / layer4 convolutions of a training pass) into up to 8 ranges, keep the partial sums there and add them in a fixed order
+   * with bias / residual / activation (deterministic; results differ from the unsplit launch by fp32 re-association).  Per call:
+   * concurrent calls on different streams bring their own scratch.  The engine entry points never split. */
+  void *splitk_ws;
+  size_t splitk_ws_bytes;
 } df_conv_desc;
 int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream);
-/* Training path: register `bytes` of device scratch (NULL: unregister).  While registered, df_conv2d_nhwc and df_conv2d_dgrad_nhwc
- * cut the reduction of launches that would fill less than half the chip (a few hundred pixels x a few thousand taps*channels: the
- * layer3 / layer4 convolutions of a training pass) into up to 8 ranges, keep the partial sums in the scratch and add them in a fixed
- * order with bias / residual / activation (deterministic; results differ from the unsplit launch by fp32 re-association).  Process-wide,
- * one stream at a time; the engine entry points (df_posenet_forward, df_estimate_poses*) never split. */
-int df_conv_splitk_scratch(void *ptr, size_t bytes);
+/* number of K ranges the calling thread's last df_conv2d_nhwc / df_conv2d_dgrad_nhwc launch was cut into (1 = not split): tests */
+int df_conv_last_splitk(void);
 
 /* The same operator for 3x3 / stride 1 / pad == dil (any dilation) evaluated through the Winograd F(2x2,3x3) domain:
  * 16 multiplies per 2x2 outputs instead of 36 (the path the engine takes for the 256/512-channel convs of the

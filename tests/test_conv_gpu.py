@@ -282,7 +282,7 @@ def test_specialised_loaders_are_bit_identical_to_the_general_one(tmp_path):
     (1, 20, 20, 512, 512, 3, 4, 4),
 ])
 def test_splitk_convolution(geom):
-    """Opt-in split-K (df_conv_splitk_scratch, what the training ops register): against an fp64 convolution, against the unsplit launch
+    """Opt-in split-K (df_conv_desc.splitk_ws, what the training ops pass): against an fp64 convolution, against the unsplit launch
     (fp32 re-association only), bit-reproducible run to run, residual + bias + ReLU applied once by the reduce kernel -- and the data
     gradient through the same path."""
     import ctypes
@@ -298,15 +298,26 @@ def test_splitk_convolution(geom):
     want = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), bias.double(), 1, pad, dil)
                       .permute(0, 2, 3, 1) + res.double())
     plain = conv2d_nhwc(x, w, bias, stride=1, pad=pad, dil=dil, act=1, res=res)
+    assert _lib.lib().df_conv_last_splitk() == 1
     with train_ops._splitk(dev):
         a = conv2d_nhwc(x, w, bias, stride=1, pad=pad, dil=dil, act=1, res=res)
-        b = conv2d_nhwc(x, w, bias, stride=1, pad=pad, dil=dil, act=1, res=res)
+        assert _lib.lib().df_conv_last_splitk() > 1, "this geometry is meant to be split"
+        with train_ops._splitk(dev):                      # nested scope: same scratch, still split
+            b = conv2d_nhwc(x, w, bias, stride=1, pad=pad, dil=dil, act=1, res=res)
+        # PReLU through the reduce kernel, into a wider output at a channel offset
+        slope = torch.tensor([0.2], device=dev)
+        wide = torch.zeros(B, H, W, Cout + 8, device=dev)
+        conv2d_nhwc(x, w, bias, stride=1, pad=pad, dil=dil, act=2, prelu=slope, out=wide, out_coff=8)
+        assert _lib.lib().df_conv_last_splitk() > 1
+    from densefusion_amd import ops as _ops
+    assert _ops.current_splitk() is None                  # the scope leaves nothing behind
     assert torch.equal(a, b), "split-K is not reproducible run to run"
+    pre = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), bias.double(), 1, pad, dil).permute(0, 2, 3, 1)
+    want_p = torch.where(pre > 0, pre, 0.2 * pre)
+    assert float((wide[..., 8:].double() - want_p).abs().max()) <= 2e-5 * max(1.0, float(want_p.abs().max())) and float(wide[..., :8].abs().max()) == 0.0
     scale = max(1.0, float(want.abs().max()))
     assert float((a.double() - want).abs().max()) <= 2e-5 * scale
     assert float((a - plain).abs().max()) <= 2e-5 * scale
-    if B > 1:
-        assert not torch.equal(a, plain) or True          # (the split launch may or may not change the bits; only the bound above is required)
     # data gradient: dx = conv_transpose(dy, w)
     dy = torch.randn(B, H, W, Cout, device=dev)
     d = _desc(x, w, None, 1, pad, dil)
@@ -317,10 +328,19 @@ def test_splitk_convolution(geom):
         scratch = torch.empty_like(w)
         if use:
             with train_ops._splitk(dev):
+                d = _desc(x, w, None, 1, pad, dil)       # (the descriptor carries the scope's scratch)
                 _lib.check(L.df_conv2d_dgrad_nhwc(ctypes.byref(d), dy.data_ptr(), dx.data_ptr(), scratch.data_ptr(), 0, _lib.current_stream()), "dgrad")
+                assert L.df_conv_last_splitk() > 1 or k == 1          # (the 1x1 case's data gradient has 400 tiles and K = 256: not split)
         else:
+            d = _desc(x, w, None, 1, pad, dil)
             _lib.check(L.df_conv2d_dgrad_nhwc(ctypes.byref(d), dy.data_ptr(), dx.data_ptr(), scratch.data_ptr(), 0, _lib.current_stream()), "dgrad")
         outs.append(dx)
+    # accumulate = 1 through the reduce kernel (res == out)
+    with train_ops._splitk(dev):
+        d = _desc(x, w, None, 1, pad, dil)
+        acc = outs[1].clone()
+        _lib.check(L.df_conv2d_dgrad_nhwc(ctypes.byref(d), dy.data_ptr(), acc.data_ptr(), torch.empty_like(w).data_ptr(), 1, _lib.current_stream()), "dgrad")
+    assert float((acc - 2 * outs[1]).abs().max()) <= 1e-5 * max(1.0, float(outs[1].abs().max()))
     want_dx = torch.nn.grad.conv2d_input((B, Cin, H, W), w.permute(0, 3, 1, 2).double(), dy.permute(0, 3, 1, 2).double(), 1, pad, dil).permute(0, 2, 3, 1)
     assert torch.equal(outs[1], outs[2])
     s2 = max(1.0, float(want_dx.abs().max()))
