@@ -192,7 +192,7 @@ def profile_gemm(pe, groups, steps):
     return tot[0], tot[1], tot[2], tot[3], tot_n
 
 
-TRAFFIC_FILE = "r02_igemm_traffic.json"
+TRAFFIC_FILE = "r03_igemm_traffic.json"
 
 
 def measured_traffic(groups, per_bucket):
@@ -279,7 +279,7 @@ def bench_knn():
               "achieved_TFLOPs": round(9.0 * Bs * R * Qs / ms_s / 1e9, 2),
               "fp32_valu_frac": round(9.0 * Bs * R * Qs / ms_s / 1e9 / FP32_PEAK_TFLOPS, 4)}
     del refs, qrys
-    return {"kernel": "knn1_dim3_kernel", "R": R, "Q": Q, "us_per_launch": round(us, 2), "stress_config5": stress,
+    return {"kernel": "knn1_dim3_sgpr_kernel (reference points through the scalar cache, 2 queries per lane)", "R": R, "Q": Q, "us_per_launch": round(us, 2), "stress_config5": stress,
             "algorithmic_bytes": byts, "achieved_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
             "algorithmic_flops": flops, "achieved_TFLOPs": round(tfl, 2), "fp32_valu_frac": round(tfl / FP32_PEAK_TFLOPS, 4),
             "bound": "fp32-valu (arithmetic intensity 9R/20 = 225 FLOP/B >> ridge ~20)"}
@@ -693,7 +693,7 @@ def main():
                        "hipgraph": graph is not None, "groups": len(groups), "group_streams": streams is not None, "steps_in_flight": len(insts), "sharding": f"objects round-robin over {world} rank(s), no data-path collective",
                        "reference_algorithm_gflop_per_step_per_gpu": round(gflop_step, 1),
                        "note": "reference_algorithm_* counts the FLOPs of the reference's own layer graph (SURVEY 8d); this build "
-                               "executes fewer (PSP fold, low-resolution up-convs, Winograd-domain trunk, chosen-pixel up_3, confidence-first heads: DESIGN.md 5), so that rate may exceed the fp32 peak"},
+                               "executes fewer (PSP fold, low-resolution up-convs, Winograd F(4x4,3x3) / F(2x2,3x3) trunk, chosen-pixel up_3, confidence-first heads: DESIGN.md 5), so that rate may exceed the fp32 peak"},
             "reference_algorithm_tflops_per_gpu": round(gflop_step * args.steps / dt / 1e3, 2),
         }
         ms, fl, useful, by, n = profile_gemm(pe, groups, min(args.steps, 5))
@@ -705,6 +705,10 @@ def main():
                            "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / FP32_PEAK_TFLOPS, 4),
                            "useful_frac": round(useful / ms / 1e9 / FP32_PEAK_TFLOPS, 4) if ms > 0 else 0.0,
+                           # the whole step against the matrix peak: the FLOPs of the step's GEMM launches on rows that are not
+                           # padding / the timed region's wall time per step (memory-bound kernels and launch gaps included)
+                           "whole_step_frac": round(fl / max(1, min(args.steps, 5)) / (dt / args.steps) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                           "whole_step_useful_frac": round(useful / max(1, min(args.steps, 5)) / (dt / args.steps) / 1e12 / FP32_PEAK_TFLOPS, 4),
                            "traffic": traffic,
                            "algorithmic_mb_per_launch": round(by / max(n, 1) / 1e6, 2),
                            "launches_per_step": n // max(1, min(args.steps, 5)),

@@ -491,20 +491,34 @@ static float *cnn_forward(Ctx &c, const std::vector<Grp> &gs, Level &half_lv) {
       for (int i : ws[r]) { t0.push_back(T); T += wino_geom(gs[i].B, li.h[i], li.w[i], dil, m).T; }
       const size_t mark = c.off;       // V / M are scratch: consecutive layers reuse the same region
       float *V = c.f((size_t)nz * T * ci), *M = c.f((size_t)nz * T * co);
-      for (size_t j = 0; j < ws[r].size(); ++j) {
-        const int i = ws[r][j];
-        if (c.live()) launch_wino_input(in + li.off[i] * ci, ci, 0, V, gs[i].B, li.h[i], li.w[i], ci, dil, c.st, T, t0[j], m);
+      // per-bucket tables of the transforms: F(4x4) runs all buckets of the route in one launch (a workgroup belongs to one bucket)
+      std::vector<int> tB, tH, tW;
+      std::vector<long> trow;
+      for (int i : ws[r]) { tB.push_back(gs[i].B); tH.push_back(li.h[i]); tW.push_back(li.w[i]); trow.push_back(li.off[i]); }
+      const int nw = (int)ws[r].size();
+      static const bool per_bucket = getenv("DF_WINO_PER_BUCKET") != nullptr;       // dev switch: one transform launch per bucket (A/B)
+      if (m == 4 && !per_bucket) {
+        if (c.live()) launch_wino4_input_multi(in, ci, V, nw, tB.data(), tH.data(), tW.data(), trow.data(), t0.data(), ci, dil, T, c.st);
+      } else {
+        for (size_t j = 0; j < ws[r].size(); ++j) {
+          const int i = ws[r][j];
+          if (c.live()) launch_wino_input(in + li.off[i] * ci, ci, 0, V, gs[i].B, li.h[i], li.w[i], ci, dil, c.st, T, t0[j], m);
+        }
       }
       ConvParams p = point_gemm(V, ci, 0, ci, c.w(key + (r ? ".wino4" : ".wino")), nullptr, M, co, 0, co, (int)T, ACT_NONE);
       p.zcount = nz; p.z_in_coff = T * ci; p.z_wgt = (long)co * ci; p.z_out_coff = T * co;
       double px = 0;        // output pixels the tiles are for: a tile yields m x m of them
       for (int i : ws[r]) px += (double)gs[i].B * li.h[i] * li.w[i];
       c.conv(p, px / ((double)(m * m) * (double)T));
-      for (size_t j = 0; j < ws[r].size(); ++j) {
-        const int i = ws[r][j];
-        if (c.live())
-          launch_wino_output(M, out + lo.off[i] * co, co, 0, nullptr, res ? res + lo.off[i] * co : nullptr, co, 0, ACT_RELU, gs[i].B, li.h[i], li.w[i],
-                             co, dil, c.st, T, t0[j], m);
+      if (m == 4 && !per_bucket) {           // (stride-1 layers: input and output levels have the same rows)
+        if (c.live()) launch_wino4_output_multi(M, out, co, res, co, ACT_RELU, nw, tB.data(), tH.data(), tW.data(), trow.data(), t0.data(), co, dil, T, c.st);
+      } else {
+        for (size_t j = 0; j < ws[r].size(); ++j) {
+          const int i = ws[r][j];
+          if (c.live())
+            launch_wino_output(M, out + lo.off[i] * co, co, 0, nullptr, res ? res + lo.off[i] * co : nullptr, co, 0, ACT_RELU, gs[i].B, li.h[i], li.w[i],
+                               co, dil, c.st, T, t0[j], m);
+        }
       }
       c.off = mark;
     }

@@ -91,12 +91,18 @@ __device__ inline void psp_bin(int bin, int &s, int &local) {
 
 // grid (50, B); thread = one float4 of channels.  Output: 4 stage blocks of B*36 rows each
 // ([4][B*36][C], stage s uses its first B*s*s rows) so the 4 stage GEMMs run as one grouped launch.
+// 1-D grid of 50 * roundup(B, 8) workgroups, XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so id % 8 picks the XCD
+// and the 50 bins of one object are given to ONE of them -- the object's map (<= 2.4 MB at 30 x 40) is fetched into that XCD's L2
+// once and the other three pyramid levels re-read it there (with the (bin, object) grid every XCD fetched every map: 3.6 TB/s of
+// reads for 0.13 of the algorithmic bandwidth).  Placement is for speed only: any placement gives the same sums.
 __global__ __launch_bounds__(512) void psp_pool_kernel(const float *__restrict__ in, int in_ld, int in_coff,
                                                        float *__restrict__ out, int B, int H, int W, int C) {
   __shared__ f32x4 s_part[4][128];
   int s, local;
-  psp_bin(blockIdx.x, s, local);
-  const int b = blockIdx.y;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int b = (q / 50) * 8 + xcd;
+  if (b >= B) return;
+  psp_bin(q % 50, s, local);
   const int i = local / s, j = local - i * s;
   const int y0 = (i * H) / s, y1 = ((i + 1) * H + s - 1) / s;     // [floor(i*H/s), ceil((i+1)*H/s))
   const int x0 = (j * W) / s, x1 = ((j + 1) * W + s - 1) / s;
@@ -163,42 +169,55 @@ __global__ __launch_bounds__(512) void psp_pool_kernel(const float *__restrict__
 // prior[b][y][x][c] = sum over the 4 pyramid stages of the bilinear (align_corners=False) resampling of
 // Z_s[b] (s x s x C) to (H, W): the PSP priors after the bottleneck 1x1 has been folded into the stage
 // weights (lib/pspnet.py:20-24; 1x1 conv and bilinear resampling are both linear and commute).
+// Workgroup = (object, 64 channels): the object's 50 stage rows of those channels (12.8 KB) and the bilinear source rows / columns /
+// weights of the four stages for every map row and column are put in LDS once (a thread used to redo the 8 source computations and
+// fetch its 16 corner vectors from L2 for every output vector: 0.20 of the algorithmic bandwidth); thread = (pixel slot, 4 channels).
+constexpr int PP_CH = 64;
 __global__ __launch_bounds__(TPB) void psp_prior_sum_kernel(const float *__restrict__ z, float *__restrict__ out, int B,
                                                             int H, int W, int C) {
-  // thread = (pixel, PV channel vectors CG apart, so that a wave's accesses stay contiguous): the bilinear source rows / columns /
-  // weights of the four stages are worked out once per thread and reused over its channels
-  constexpr int PV = 4;
-  const int C4 = C / 4, CG = C4 / PV;                     // C % 16 == 0 (1024 here)
-  const long total = (long)B * H * W * CG;
-  for (long idx = blockIdx.x * (long)TPB + threadIdx.x; idx < total; idx += (long)gridDim.x * TPB) {
-    const int cg = (int)(idx % CG);
-    long r = idx / CG;
-    const int x = (int)(r % W); r /= W;
-    const int y = (int)(r % H);
-    const int b = (int)(r / H);
-    f32x4 acc[PV];
-#pragma unroll
-    for (int v = 0; v < PV; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+  extern __shared__ __attribute__((aligned(16))) float s_pp[];      // [50][64] stage rows, then the row / column tables
+  f32x4 *s_z = reinterpret_cast<f32x4 *>(s_pp);
+  int *s_i = reinterpret_cast<int *>(s_pp + 50 * PP_CH);               // [4][H + W][2] first / second source index
+  float *s_w = reinterpret_cast<float *>(s_i + 8 * (H + W));           // [4][H + W][2] their weights
+  const int chunks = C / PP_CH;
+  const int b = blockIdx.x / chunks, c0 = (blockIdx.x % chunks) * PP_CH;
+  for (int i = threadIdx.x; i < 50 * (PP_CH / 4); i += TPB) {
+    const int row = i / (PP_CH / 4), v = i % (PP_CH / 4);
+    int s, local;
+    psp_bin(row, s, local);
+    const int stage = s == 1 ? 0 : s == 2 ? 1 : s == 3 ? 2 : 3;
+    s_z[i] = *reinterpret_cast<const f32x4 *>(z + ((size_t)stage * B * 36 + (size_t)b * s * s + local) * C + c0 + v * 4);
+  }
+  for (int i = threadIdx.x; i < 4 * (H + W); i += TPB) {
+    const int stage = i / (H + W), p = i % (H + W);
+    const int s = stage == 0 ? 1 : stage == 1 ? 2 : stage == 2 ? 3 : 6;
+    int i0, i1;
+    float l0, l1;
+    if (p < H) src_hp(p, (float)s / (float)H, s, i0, i1, l0, l1);
+    else src_hp(p - H, (float)s / (float)W, s, i0, i1, l0, l1);
+    s_i[2 * i] = i0; s_i[2 * i + 1] = i1;
+    s_w[2 * i] = l0; s_w[2 * i + 1] = l1;
+  }
+  __syncthreads();
+  const int v = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  const int base_of[4] = {0, 1, 5, 14};                       // first stage row of s = 1, 2, 3, 6 among the 50
+  for (int p = slot; p < H * W; p += TPB / 16) {
+    const int y = p / W, x = p - y * W;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int stage = 0; stage < 4; ++stage) {
       const int s = stage == 0 ? 1 : stage == 1 ? 2 : stage == 2 ? 3 : 6;
-      int y0, y1, x0, x1;
-      float wy0, wy1, wx0, wx1;
-      src_hp(y, (float)s / (float)H, s, y0, y1, wy0, wy1);
-      src_hp(x, (float)s / (float)W, s, x0, x1, wx0, wx1);
-      const f32x4 *src = reinterpret_cast<const f32x4 *>(z + ((size_t)stage * B * 36 + (size_t)b * s * s) * C) + cg;
+      const int ty = (stage * (H + W) + y) * 2, tx = (stage * (H + W) + H + x) * 2;
+      const int y0 = s_i[ty], y1 = s_i[ty + 1], x0 = s_i[tx], x1 = s_i[tx + 1];
+      const float wy0 = s_w[ty], wy1 = s_w[ty + 1], wx0 = s_w[tx], wx1 = s_w[tx + 1];
+      const f32x4 *src = s_z + base_of[stage] * (PP_CH / 4) + v;
+      const f32x4 v00 = src[(y0 * s + x0) * (PP_CH / 4)], v01 = src[(y0 * s + x1) * (PP_CH / 4)];
+      const f32x4 v10 = src[(y1 * s + x0) * (PP_CH / 4)], v11 = src[(y1 * s + x1) * (PP_CH / 4)];
+      const f32x4 t = lerp4(v00, v01, v10, v11, wy0, wy1, wx0, wx1);
 #pragma unroll
-      for (int v = 0; v < PV; ++v) {
-        const f32x4 v00 = src[(y0 * s + x0) * C4 + v * CG], v01 = src[(y0 * s + x1) * C4 + v * CG];
-        const f32x4 v10 = src[(y1 * s + x0) * C4 + v * CG], v11 = src[(y1 * s + x1) * C4 + v * CG];
-        const f32x4 t = lerp4(v00, v01, v10, v11, wy0, wy1, wx0, wx1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[v][e] += t[e];
-      }
+      for (int e = 0; e < 4; ++e) acc[e] += t[e];
     }
-    f32x4 *dst = reinterpret_cast<f32x4 *>(out) + (idx / CG) * C4 + cg;
-#pragma unroll
-    for (int v = 0; v < PV; ++v) dst[v * CG] = acc[v];
+    *reinterpret_cast<f32x4 *>(out + ((size_t)b * H * W + p) * C + c0 + v * 4) = acc;
   }
 }
 
@@ -238,6 +257,9 @@ __global__ __launch_bounds__(512) void upconv_gather_tiled_kernel(const float *_
                                                                   const float *__restrict__ prelu, float *__restrict__ out, int B,
                                                                   int h, int w, int Cout) {
   __shared__ __attribute__((aligned(16))) float s_y[UG_RH * UG_RW * 9 * UG_CC];
+  // per tile row / column and tap: the two LDS offsets and weights of the bilinear source (zero weights for taps outside the image):
+  // worked out once per workgroup by 72 threads instead of six source computations in every thread
+  __shared__ __attribute__((aligned(16))) int s_trow[3 * UG_TY][4], s_tcol[3 * UG_TX][4];
   const int OH = 2 * h, OW = 2 * w, ldy = 9 * Cout, chunks = Cout / UG_CC;
   const float sh = OH > 1 ? (float)(h - 1) / (float)(OH - 1) : 0.f;
   const float sw = OW > 1 ? (float)(w - 1) / (float)(OW - 1) : 0.f;
@@ -269,22 +291,38 @@ __global__ __launch_bounds__(512) void upconv_gather_tiled_kernel(const float *_
       }
     }
   }
+  if (threadIdx.x >= 512 - 3 * (UG_TY + UG_TX)) {          // the last 72 threads fill the tables (24 row entries, 48 column entries)
+    const int e = threadIdx.x - (512 - 3 * (UG_TY + UG_TX));
+    const bool row = e < 3 * UG_TY;
+    const int k = row ? e : e - 3 * UG_TY;
+    const int d = row ? k / UG_TY : k / UG_TX, l = row ? k % UG_TY : k % UG_TX;
+    const int q = (row ? Y0 : X0) + l + d - 1;
+    const bool ok = (unsigned)q < (unsigned)(row ? OH : OW);
+    int i0, i1;
+    float w0, w1;
+    src_ac(ok ? q : 0, row ? sh : sw, row ? h : w, i0, i1, w0, w1);
+    int *dst = row ? s_trow[k] : s_tcol[k];
+    const int unit = row ? UG_RW * 36 : 36, lo = row ? r_lo : c_lo;
+    dst[0] = ok ? (i0 - lo) * unit : 0;
+    dst[1] = ok ? (i1 - lo) * unit : 0;
+    dst[2] = __float_as_int(ok ? w0 : 0.f);
+    dst[3] = __float_as_int(ok ? w1 : 0.f);
+  }
   __syncthreads();
   const int c4 = threadIdx.x & 3, pt = threadIdx.x >> 2;
-  const int py = Y0 + pt / UG_TX, px = X0 + pt % UG_TX;
+  const int ly = pt / UG_TX, lx = pt % UG_TX;
+  const int py = Y0 + ly, px = X0 + lx;
   if (py >= OH || px >= OW) return;
-  const Tap3 ty = taps_for(py, sh, h, OH), tx = taps_for(px, sw, w, OW);
   // LDS vector index of (row a of tap row dy) / (column b of tap column dx); weights of taps outside the image are zero
   int ro[3][2], co[3][2];
   float wy[3][2], wx[3][2];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    ro[d][0] = (ty.ok[d] ? ty.i0[d] - r_lo : 0) * (UG_RW * 36);
-    ro[d][1] = (ty.ok[d] ? ty.i1[d] - r_lo : 0) * (UG_RW * 36);
-    co[d][0] = (tx.ok[d] ? tx.i0[d] - c_lo : 0) * 36 + c4;
-    co[d][1] = (tx.ok[d] ? tx.i1[d] - c_lo : 0) * 36 + c4;
-    wy[d][0] = ty.ok[d] ? ty.w0[d] : 0.f; wy[d][1] = ty.ok[d] ? ty.w1[d] : 0.f;
-    wx[d][0] = tx.ok[d] ? tx.w0[d] : 0.f; wx[d][1] = tx.ok[d] ? tx.w1[d] : 0.f;
+    const int4 tr = *reinterpret_cast<const int4 *>(s_trow[d * UG_TY + ly]), tc = *reinterpret_cast<const int4 *>(s_tcol[d * UG_TX + lx]);
+    ro[d][0] = tr.x; ro[d][1] = tr.y;
+    co[d][0] = tc.x + c4; co[d][1] = tc.y + c4;
+    wy[d][0] = __int_as_float(tr.z); wy[d][1] = __int_as_float(tr.w);
+    wx[d][0] = __int_as_float(tc.z); wx[d][1] = __int_as_float(tc.w);
   }
   const float slope = prelu[0];
   f32x4 acc = *reinterpret_cast<const f32x4 *>(bias + c0 + c4 * 4);
@@ -579,10 +617,11 @@ void launch_maxpool3s2(const float *in, float *out, int B, int H, int W, int C, 
                      C / 4, OH, OW);
 }
 void launch_psp_pool(const float *in, int in_ld, int in_coff, float *out, int B, int H, int W, int C, hipStream_t st) {
-  hipLaunchKernelGGL(psp_pool_kernel, dim3(50, B), dim3(512), 0, st, in, in_ld, in_coff, out, B, H, W, C);
+  hipLaunchKernelGGL(psp_pool_kernel, dim3(50 * ((B + 7) / 8) * 8), dim3(512), 0, st, in, in_ld, in_coff, out, B, H, W, C);
 }
 void launch_psp_prior_sum(const float *z, float *out, int B, int H, int W, int C, hipStream_t st) {
-  hipLaunchKernelGGL(psp_prior_sum_kernel, dim3(blocks_for((long)B * H * W * (C / 16))), dim3(TPB), 0, st, z, out, B, H, W, C);
+  const size_t lds = ((size_t)50 * PP_CH + (size_t)16 * (H + W)) * sizeof(float);          // C % 64 == 0 (1024 here); H + W <= 1120
+  hipLaunchKernelGGL(psp_prior_sum_kernel, dim3(B * (C / PP_CH)), dim3(TPB), lds, st, z, out, B, H, W, C);
 }
 void launch_up3_patches(const float *x, const int64_t *choose, float *patch, int B, int h, int wd, int N, int Npad, hipStream_t st) {
   hipLaunchKernelGGL(up3_patch_kernel, dim3(blocks_for((long)B * Npad * 9 * 16)), dim3(TPB), 0, st, x, choose, patch, B, h, wd, N, Npad);

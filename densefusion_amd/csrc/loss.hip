@@ -8,6 +8,8 @@
 // the M target points sit in LDS (broadcast reads), and neither the [N,M,3] prediction nor the index
 // tensor ever reaches HBM.  The nearest-neighbour choice uses the same arithmetic as csrc/knn.hip
 // (fma chain in coordinate order, strict '<', lowest index wins).
+#include <algorithm>
+
 #include "common.h"
 #include "knn_core.h"
 
@@ -439,7 +441,7 @@ extern "C" int df_loss_forward(const float *pred_r, const float *pred_t, const f
   hipStream_t st = to_stream(stream);
   const size_t lds = (size_t)M * 16;
   loss_lds_attrs();
-  const int ppb = M >= LB * SYM_QPL ? 1 : (LB * SYM_QPL) / M;
+  const int ppb = M >= LB * SYM_QPL ? 1 : std::min(LB, (LB * SYM_QPL) / M);      // (the per-pose totals are kept by tid < ppb <= LB)
   const size_t lds2 = (size_t)M * 16 + (size_t)LB * SYM_QPL * 4 + (size_t)ppb * 4;
   if (symmetric && N >= 2 && lds2 <= 150 * 1024) {
     // the fused transform + shared 1-NN scan (knn_core.h) + distance reduction; ppb whole poses per workgroup fill its

@@ -4,6 +4,9 @@
 
 namespace df {
 
+constexpr int WINO_MAXB = 16;
+// per-bucket table of a multi-bucket transform launch (kernel argument, by value)
+struct WinoTab { int n; int H[WINO_MAXB], W[WINO_MAXB], TH[WINO_MAXB], TW[WINO_MAXB], blocks[WINO_MAXB + 1]; long T[WINO_MAXB], row0[WINO_MAXB], t0[WINO_MAXB]; };
 struct WinoGeom { int TH, TW; long T; };                 // tiles per sub-lattice (rows, columns), tiles in total
 // m = 2: F(2x2,3x3) (16 planes), m = 4: F(4x4,3x3) (36 planes)
 WinoGeom wino_geom(int B, int H, int W, int dil, int m = 2);
@@ -17,5 +20,11 @@ void launch_wino_input(const float *x, int in_ld, int in_coff, float *V /*[(m+2)
 void launch_wino_output(const float *M /*[(m+2)^2][Ttot][C]*/, float *out, int out_ld, int out_coff, const float *bias, const float *res,
                         int res_ld, int res_coff, int act, int B, int H, int W, int C, int dil, hipStream_t st, long Ttot = 0, long t0 = 0,
                         int m = 2);
+
+// F(4x4,3x3) transforms of nb crop-size buckets in one launch per 16 buckets (B / H / W / first pixel row / first tile per bucket)
+void launch_wino4_input_multi(const float *x, int in_ld, float *V, int nb, const int *B, const int *H, const int *W, const long *row0, const long *t0,
+                              int C, int dil, long Ttot, hipStream_t st);
+void launch_wino4_output_multi(const float *M, float *out, int out_ld, const float *res, int res_ld, int act, int nb, const int *B, const int *H,
+                               const int *W, const long *row0, const long *t0, int C, int dil, long Ttot, hipStream_t st);
 
 }  // namespace df

@@ -196,11 +196,11 @@ __global__ __launch_bounds__(WB) void wino4_weight_kernel(const float *__restric
 }
 
 // V[z = i*6+j][t][c] = (B^T d B)[i][j]; one thread per (tile, 4 channels): 36 vector loads in flight per thread
-__global__ __launch_bounds__(WB) void wino4_input_kernel(const float *__restrict__ x, int in_ld, int in_coff, float *__restrict__ V, int H,
-                                                         int W, int C, int d, int TH, int TW, long T, long Ttot, long t0) {
+__device__ __forceinline__ void wino4_input_body(const float *__restrict__ x, int in_ld, int in_coff, float *__restrict__ V, int H, int W, int C, int d,
+                                                 int TH, int TW, long T, long Ttot, long t0, long e_begin, long e_step) {
   const int c4n = C >> 2;
   const long total = T * c4n;
-  for (long e = (long)blockIdx.x * WB + threadIdx.x; e < total; e += (long)gridDim.x * WB) {
+  for (long e = e_begin; e < total; e += e_step) {
     const int c = (int)(e % c4n) << 2;
     const long t = e / c4n;
     const TileId id = tile_of((int)t, d, TH, TW);
@@ -240,14 +240,27 @@ __device__ __forceinline__ void at6(const float4 m0, const float4 m1, const floa
   y[3 * stride] = f4add(f4add(d12, m5), f4add(f4s(0.125f, m3), f4s(-8.f, m4)));
 }
 
+__global__ __launch_bounds__(WB) void wino4_input_kernel(const float *__restrict__ x, int in_ld, int in_coff, float *__restrict__ V, int H,
+                                                         int W, int C, int d, int TH, int TW, long T, long Ttot, long t0) {
+  wino4_input_body(x, in_ld, in_coff, V, H, W, C, d, TH, TW, T, Ttot, t0, (long)blockIdx.x * WB + threadIdx.x, (long)gridDim.x * WB);
+}
+// the same for up to WINO_MAXB crop-size buckets in ONE launch: a workgroup belongs to one bucket (blocks[k] .. blocks[k + 1]), found by
+// a wave-uniform scan of the table in the kernel arguments
+__global__ __launch_bounds__(WB) void wino4_input_multi_kernel(const float *__restrict__ x, int in_ld, float *__restrict__ V, int C, int d, long Ttot,
+                                                               const WinoTab tab) {
+  int k = 0;
+  while (k + 1 < tab.n && (int)blockIdx.x >= tab.blocks[k + 1]) ++k;
+  wino4_input_body(x + tab.row0[k] * in_ld, in_ld, 0, V, tab.H[k], tab.W[k], C, d, tab.TH[k], tab.TW[k], tab.T[k], Ttot, tab.t0[k],
+                   (long)((int)blockIdx.x - tab.blocks[k]) * WB + threadIdx.x, (long)(tab.blocks[k + 1] - tab.blocks[k]) * WB);
+}
+
 // out = act( A^T M A + bias + res ); one thread per (tile, 4 output channels)
-__global__ __launch_bounds__(WB) void wino4_output_kernel(const float *__restrict__ Mz, float *__restrict__ out, int out_ld, int out_coff,
-                                                          const float *__restrict__ bias, const float *__restrict__ res, int res_ld,
-                                                          int res_coff, int act, int H, int W, int C, int d, int TH, int TW, long T,
-                                                          long Ttot, long t0) {
+__device__ __forceinline__ void wino4_output_body(const float *__restrict__ Mz, float *__restrict__ out, int out_ld, int out_coff,
+                                                  const float *__restrict__ bias, const float *__restrict__ res, int res_ld, int res_coff, int act, int H,
+                                                  int W, int C, int d, int TH, int TW, long T, long Ttot, long t0, long e_begin, long e_step) {
   const int c4n = C >> 2;
   const long total = T * c4n;
-  for (long e = (long)blockIdx.x * WB + threadIdx.x; e < total; e += (long)gridDim.x * WB) {
+  for (long e = e_begin; e < total; e += e_step) {
     const int c = (int)(e % c4n) << 2;
     const long t = e / c4n;
     const TileId id = tile_of((int)t, d, TH, TW);
@@ -281,6 +294,22 @@ __global__ __launch_bounds__(WB) void wino4_output_kernel(const float *__restric
       }
     }
   }
+}
+
+__global__ __launch_bounds__(WB) void wino4_output_kernel(const float *__restrict__ Mz, float *__restrict__ out, int out_ld, int out_coff,
+                                                          const float *__restrict__ bias, const float *__restrict__ res, int res_ld,
+                                                          int res_coff, int act, int H, int W, int C, int d, int TH, int TW, long T,
+                                                          long Ttot, long t0) {
+  wino4_output_body(Mz, out, out_ld, out_coff, bias, res, res_ld, res_coff, act, H, W, C, d, TH, TW, T, Ttot, t0,
+                    (long)blockIdx.x * WB + threadIdx.x, (long)gridDim.x * WB);
+}
+__global__ __launch_bounds__(WB) void wino4_output_multi_kernel(const float *__restrict__ Mz, float *__restrict__ out, int out_ld, const float *__restrict__ res,
+                                                                int res_ld, int act, int C, int d, long Ttot, const WinoTab tab) {
+  int k = 0;
+  while (k + 1 < tab.n && (int)blockIdx.x >= tab.blocks[k + 1]) ++k;
+  wino4_output_body(Mz, out + tab.row0[k] * out_ld, out_ld, 0, nullptr, res ? res + tab.row0[k] * res_ld : nullptr, res_ld, 0, act, tab.H[k], tab.W[k], C,
+                    d, tab.TH[k], tab.TW[k], tab.T[k], Ttot, tab.t0[k], (long)((int)blockIdx.x - tab.blocks[k]) * WB + threadIdx.x,
+                    (long)(tab.blocks[k + 1] - tab.blocks[k]) * WB);
 }
 
 inline unsigned blocks_for(long n) {
@@ -344,6 +373,38 @@ void launch_wino_output(const float *M, float *out, int out_ld, int out_coff, co
   else
     hipLaunchKernelGGL(wino_output_kernel, dim3(blocks_for(g.T * (C / 4))), dim3(WB), 0, st, M, out, out_ld, out_coff, bias, res, res_ld,
                        res_coff, act, H, W, C, dil, g.TH, g.TW, g.T, Ttot, t0);
+}
+
+// F(4x4,3x3) transforms of several crop-size buckets in one launch each (chunks of WINO_MAXB buckets): bucket k = B[k] maps of
+// H[k] x W[k] whose pixel rows start at row0[k] of x / out / res, and whose tiles are rows t0[k] .. of the Ttot-row planes
+static WinoTab make_tab(int n, const int *B, const int *H, const int *W, const long *row0, const long *t0, int C, int dil) {
+  WinoTab tab;
+  tab.n = n;
+  tab.blocks[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    const WinoGeom g = wino_geom(B[k], H[k], W[k], dil, 4);
+    tab.H[k] = H[k]; tab.W[k] = W[k]; tab.TH[k] = g.TH; tab.TW[k] = g.TW; tab.T[k] = g.T; tab.row0[k] = row0[k]; tab.t0[k] = t0[k];
+    tab.blocks[k + 1] = tab.blocks[k] + (int)blocks_for(g.T * (C / 4));
+  }
+  return tab;
+}
+
+void launch_wino4_input_multi(const float *x, int in_ld, float *V, int nb, const int *B, const int *H, const int *W, const long *row0, const long *t0,
+                              int C, int dil, long Ttot, hipStream_t st) {
+  for (int k0 = 0; k0 < nb; k0 += WINO_MAXB) {
+    const int n = nb - k0 < WINO_MAXB ? nb - k0 : WINO_MAXB;
+    const WinoTab tab = make_tab(n, B + k0, H + k0, W + k0, row0 + k0, t0 + k0, C, dil);
+    hipLaunchKernelGGL(wino4_input_multi_kernel, dim3(tab.blocks[n]), dim3(WB), 0, st, x, in_ld, V, C, dil, Ttot, tab);
+  }
+}
+
+void launch_wino4_output_multi(const float *M, float *out, int out_ld, const float *res, int res_ld, int act, int nb, const int *B, const int *H,
+                               const int *W, const long *row0, const long *t0, int C, int dil, long Ttot, hipStream_t st) {
+  for (int k0 = 0; k0 < nb; k0 += WINO_MAXB) {
+    const int n = nb - k0 < WINO_MAXB ? nb - k0 : WINO_MAXB;
+    const WinoTab tab = make_tab(n, B + k0, H + k0, W + k0, row0 + k0, t0 + k0, C, dil);
+    hipLaunchKernelGGL(wino4_output_multi_kernel, dim3(tab.blocks[n]), dim3(WB), 0, st, M, out, out_ld, res, res_ld, act, C, dil, Ttot, tab);
+  }
 }
 
 }  // namespace df

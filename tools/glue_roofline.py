@@ -1,12 +1,11 @@
 """Dev tool: achieved HBM GB/s of the memory-bound glue kernels of one bench step against their algorithmic bytes.
 
-    python tools/glue_roofline.py KERNEL_STATS.csv PASSES OUT.json
+    python tools/glue_roofline.py SERIAL_LAST_PASS.json OUT.json
 
-KERNEL_STATS.csv: `rocprofv3 --kernel-trace --stats` of a SERIAL bench run (tools/dev/prof_serial.sh: one stream, no graph,
---groups 1), PASSES = number of passes over the step's 280 objects in that run (eager + warm-up + timed + profiled steps).
+SERIAL_LAST_PASS.json: tools/trace_summary.py over the kernel trace of a SERIAL bench run (tools/dev/prof_serial.sh: one stream, no
+graph, --groups 1): per kernel the time of the run's last pass over the step's 280 objects (the first passes touch fresh pages).
 Algorithmic bytes (every tensor a kernel must read / write, once, fp32) are computed here from the bench workload: K = 21,
 N = 1000 (Npad = 1024), 40 objects of each of the seven crop sizes, 2 refine iterations."""
-import csv
 import json
 import sys
 
@@ -66,21 +65,23 @@ def step_bytes():
 
 
 def main():
-    path, passes, out = sys.argv[1], float(sys.argv[2]), sys.argv[3]
+    path, out = sys.argv[1], sys.argv[2]
     alg = step_bytes()
+    alg["wino4_input_multi_kernel"] = alg.pop("wino4_input_kernel", 0.0)          # the F(4x4) transforms run all buckets in one launch
+    alg["wino4_output_multi_kernel"] = alg.pop("wino4_output_kernel", 0.0)
+    last = json.load(open(path))
     rows = []
-    with open(path, newline="") as f:
-        for r in csv.DictReader(f):
-            for k in alg:
-                if k + "(" in r["Name"] or k + "<" in r["Name"] or r["Name"].endswith(k):
-                    us = int(r["TotalDurationNs"]) / passes / 1e3
-                    gbs = alg[k] / us / 1e3
-                    rows.append({"kernel": k, "calls_per_step": round(int(r["Calls"]) / passes, 1), "us_per_step": round(us, 1),
-                                 "algorithmic_mb_per_step": round(alg[k] / 1e6, 1), "achieved_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM, 3)})
+    for r in last["kernels"]:
+        k = r["kernel"]
+        if k in alg and alg[k] > 0:
+            us = r["us_per_step"]
+            gbs = alg[k] / us / 1e3
+            rows.append({"kernel": k, "calls_per_step": r["calls_per_step"], "us_per_step": us, "algorithmic_mb_per_step": round(alg[k] / 1e6, 1),
+                         "achieved_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM, 3)})
     rows.sort(key=lambda r: -r["us_per_step"])
-    res = {"workload": "bench.py step: 280 objects (40 of each of 7 crop sizes), N=1000, 2 refine iterations; serial run (one stream, no graph, --groups 1)",
-           "hbm_peak_GBps": HBM, "source_csv": path, "passes": passes, "kernels": rows,
-           "glue_us_per_step": round(sum(r["us_per_step"] for r in rows), 1)}
+    res = {"workload": "bench.py step: 280 objects (40 of each of 7 crop sizes), N=1000, 2 refine iterations; serial run (one stream, no graph, --groups 1); "
+                       "steady state = the LAST pass of the trace (tools/trace_summary.py)",
+           "hbm_peak_GBps": HBM, "source": path, "kernels": rows, "glue_us_per_step": round(sum(r["us_per_step"] for r in rows), 1)}
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     for r in rows:

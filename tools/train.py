@@ -88,6 +88,9 @@ def build_parser():
     ap.add_argument("--noise_trans", type=float, default=0.03)
     ap.add_argument("--iteration", type=int, default=2)
     ap.add_argument("--nepoch", type=int, default=500)
+    ap.add_argument("--repeat_epoch", type=int, default=0,
+                    help="passes over the training set per epoch, i.e. per test pass / decay check / refine check (tools/train.py:61-73,143 of the "
+                         "reference: 20 for linemod, 1 otherwise); 0 = that rule")
     ap.add_argument("--resume_posenet", type=str, default="")
     ap.add_argument("--resume_refinenet", type=str, default="")
     ap.add_argument("--start_epoch", type=int, default=1)
@@ -161,6 +164,8 @@ def main(argv=None):
         opt.lr *= opt.lr_rate
         opt.w *= opt.w_rate
         opt.batch_size = max(1, int(opt.batch_size / opt.iteration))
+    if opt.repeat_epoch <= 0:
+        opt.repeat_epoch = 20 if opt.dataset == "linemod" else 1
     dataset, test_dataset = make_datasets(opt)
     estimator = PoseNet(num_points=opt.num_points, num_obj=opt.num_objects).to(dev)
     refiner = PoseRefineNet(num_points=opt.num_points, num_obj=opt.num_objects).to(dev)
@@ -298,12 +303,13 @@ def main(argv=None):
         # disjoint; all ranks take the same number of frames and therefore the same number of optimizer steps -- the gradient
         # all-reduce is a collective, a rank that ran one step fewer would leave the others waiting in it.  Lost-detection
         # sentinels (LineMOD) count toward the window like any frame: they add no gradient but never skip a collective.
-        perm = np.random.RandomState(opt.seed + epoch).permutation(len(dataset))
         steps = len(dataset) // (world * opt.batch_size)
         if steps == 0:
             log.warning("epoch %d: %d training frames are fewer than ranks x batch_size = %d: no optimizer step this epoch", epoch, len(dataset),
                         world * opt.batch_size)
-        order = perm[:steps * world * opt.batch_size][rank::world]
+        # `repeat_epoch` passes over the set per epoch, each with its own permutation (seed, epoch, pass) shared by every rank
+        order = np.concatenate([np.random.RandomState((opt.seed + epoch) * 1009 + rep).permutation(len(dataset))[:steps * world * opt.batch_size][rank::world]
+                                for rep in range(opt.repeat_epoch)]) if steps else np.zeros(0, dtype=np.int64)
         window, slots = [], 0
         window_dis = torch.zeros((), device=dev)
         for item in train_utils.Prefetcher(dataset, order, dev, workers=opt.workers):
