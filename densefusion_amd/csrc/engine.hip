@@ -390,6 +390,12 @@ struct Ctx {
 static ConvParams point_gemm(const float *in, int in_ld, int in_coff, int cin, const float *w, const float *bias,
                              float *out, int out_ld, int out_coff, int cout, int rows, int act);
 
+// dev switch (A/B runs): DF_POINT_UNFUSED = the K = 3 / 32 / 64 per-point layers as separate launches (round 2) instead of pointfeat.hip
+static bool point_fused() {
+  static const bool on = getenv("DF_POINT_UNFUSED") == nullptr;
+  return on;
+}
+
 // dev switches (A/B runs): DF_NO_WINOGRAD = direct convolutions only, DF_WINOGRAD_TILE = 2 keeps F(2x2,3x3) where a Winograd route pays
 static int wino_route_for(int H, int W, int dil, int ci, int co) {
   static const bool off = getenv("DF_NO_WINOGRAD") != nullptr;
@@ -620,10 +626,19 @@ static void posenet_points(Ctx &c, int B, int N, int Npad, const float *cloud, c
   Net &n = *c.net;
   const int rows = B * Npad;
   float *pf = c.f((size_t)rows * 384);          // [x1 64 | e1 64 | x2 128 | e2 128] = pointfeat_1 | pointfeat_2
-  if (c.live()) launch_cloud_conv1(cloud, nullptr, c.w("feat.conv1.weight"), c.w("feat.conv1.bias"), pf, 384, B, N, Npad, c.st);
-  c.pconv(point_gemm(emb_pm, 32, 0, 32, c.w("feat.e_conv1.weight"), c.w("feat.e_conv1.bias"), pf, 384, 64, 64, rows, ACT_RELU));
-  c.pconv(point_gemm(pf, 384, 0, 64, c.w("feat.conv2.weight"), c.w("feat.conv2.bias"), pf, 384, 128, 128, rows, ACT_RELU));
-  c.pconv(point_gemm(pf, 384, 64, 64, c.w("feat.e_conv2.weight"), c.w("feat.e_conv2.bias"), pf, 384, 256, 128, rows, ACT_RELU));
+  if (point_fused()) {        // conv1 -> conv2 and e_conv1 -> e_conv2 chained in one launch, the 64-wide intermediates in LDS
+    PointFeatParams q;
+    q.cloud = cloud; q.emb = emb_pm; q.pf = pf; q.ld = 384; q.cx1 = 0; q.ce1 = 64; q.cx2 = 128; q.ce2 = 256;
+    q.w1 = c.w("feat.conv1.weight"); q.b1 = c.w("feat.conv1.bias"); q.w2 = c.w("feat.conv2.weight"); q.b2 = c.w("feat.conv2.bias");
+    q.we1 = c.w("feat.e_conv1.weight"); q.be1 = c.w("feat.e_conv1.bias"); q.we2 = c.w("feat.e_conv2.weight"); q.be2 = c.w("feat.e_conv2.bias");
+    q.B = B; q.N = N; q.Npad = Npad;
+    if (c.live()) { const int rc = launch_pointfeat(q, c.st); if (rc != DF_OK) c.err = rc; }
+  } else {
+    if (c.live()) launch_cloud_conv1(cloud, nullptr, c.w("feat.conv1.weight"), c.w("feat.conv1.bias"), pf, 384, B, N, Npad, c.st);
+    c.pconv(point_gemm(emb_pm, 32, 0, 32, c.w("feat.e_conv1.weight"), c.w("feat.e_conv1.bias"), pf, 384, 64, 64, rows, ACT_RELU));
+    c.pconv(point_gemm(pf, 384, 0, 64, c.w("feat.conv2.weight"), c.w("feat.conv2.bias"), pf, 384, 128, 128, rows, ACT_RELU));
+    c.pconv(point_gemm(pf, 384, 64, 64, c.w("feat.e_conv2.weight"), c.w("feat.e_conv2.bias"), pf, 384, 256, 128, rows, ACT_RELU));
+  }
   float *x5 = c.f((size_t)rows * 512);
   c.pconv(point_gemm(pf, 384, 128, 256, c.w("feat.conv5.weight"), c.w("feat.conv5.bias"), x5, 512, 0, 512, rows, ACT_RELU));
   // conv6 + ReLU + AvgPool1d(N): the 1024-wide activation is consumed only by the mean, so it never
@@ -734,8 +749,16 @@ static RefinerBufs refiner_alloc(Ctx &c, int B, int N, int Npad) {
 
 static void refiner_prepare(Ctx &c, const RefinerBufs &r, int B, int Npad, const float *emb_pm) {
   const int rows = B * Npad;
-  c.pconv(point_gemm(emb_pm, 32, 0, 32, c.w("feat.e_conv1.weight"), c.w("feat.e_conv1.bias"), r.pf, 384, 192, 64, rows, ACT_RELU));
-  c.pconv(point_gemm(r.pf, 384, 192, 64, c.w("feat.e_conv2.weight"), c.w("feat.e_conv2.bias"), r.pf, 384, 256, 128, rows, ACT_RELU));
+  if (point_fused()) {
+    PointFeatParams q;
+    q.emb = emb_pm; q.pf = r.pf; q.ld = 384; q.ce1 = 192; q.ce2 = 256;
+    q.we1 = c.w("feat.e_conv1.weight"); q.be1 = c.w("feat.e_conv1.bias"); q.we2 = c.w("feat.e_conv2.weight"); q.be2 = c.w("feat.e_conv2.bias");
+    q.B = B; q.N = c.net->num_points; q.Npad = Npad;
+    if (c.live()) { const int rc = launch_pointfeat(q, c.st); if (rc != DF_OK) c.err = rc; }
+  } else {
+    c.pconv(point_gemm(emb_pm, 32, 0, 32, c.w("feat.e_conv1.weight"), c.w("feat.e_conv1.bias"), r.pf, 384, 192, 64, rows, ACT_RELU));
+    c.pconv(point_gemm(r.pf, 384, 192, 64, c.w("feat.e_conv2.weight"), c.w("feat.e_conv2.bias"), r.pf, 384, 256, 128, rows, ACT_RELU));
+  }
   // colour half of conv5 (+ its bias), once per object; the iterations add the xyz half and apply the ReLU
   c.pconv(point_gemm(r.pf, 384, 192, 192, c.w("feat.conv5.we"), c.w("feat.conv5.bias"), r.e5, 512, 0, 512, rows, ACT_NONE));
 }
@@ -743,8 +766,16 @@ static void refiner_prepare(Ctx &c, const RefinerBufs &r, int B, int Npad, const
 static void refiner_iterate(Ctx &c, const RefinerBufs &r, int B, int N, int Npad, const float *cloud, const float *rt,
                             const int64_t *obj, float *out_r, float *out_t, double *state, float *rt_next, double *pose_out) {
   const int rows = B * Npad;
-  if (c.live()) launch_cloud_conv1(cloud, rt, c.w("feat.conv1.weight"), c.w("feat.conv1.bias"), r.pf, 384, B, N, Npad, c.st);
-  c.pconv(point_gemm(r.pf, 384, 0, 64, c.w("feat.conv2.weight"), c.w("feat.conv2.bias"), r.pf, 384, 64, 128, rows, ACT_RELU));
+  if (point_fused()) {
+    PointFeatParams q;
+    q.cloud = cloud; q.rt = rt; q.pf = r.pf; q.ld = 384; q.cx1 = 0; q.cx2 = 64;
+    q.w1 = c.w("feat.conv1.weight"); q.b1 = c.w("feat.conv1.bias"); q.w2 = c.w("feat.conv2.weight"); q.b2 = c.w("feat.conv2.bias");
+    q.B = B; q.N = N; q.Npad = Npad;
+    if (c.live()) { const int rc = launch_pointfeat(q, c.st); if (rc != DF_OK) c.err = rc; }
+  } else {
+    if (c.live()) launch_cloud_conv1(cloud, rt, c.w("feat.conv1.weight"), c.w("feat.conv1.bias"), r.pf, 384, B, N, Npad, c.st);
+    c.pconv(point_gemm(r.pf, 384, 0, 64, c.w("feat.conv2.weight"), c.w("feat.conv2.bias"), r.pf, 384, 64, 128, rows, ACT_RELU));
+  }
   {
     ConvParams p = point_gemm(r.pf, 384, 0, 192, c.w("feat.conv5.wx"), nullptr, r.x5, 512, 0, 512, rows, ACT_RELU);
     p.res = r.e5; p.res_ld = 512;

@@ -33,6 +33,19 @@ void launch_emb_to_pm(const float *emb, float *emb_pm, int B, int N, int Npad, h
 // new = (p - T[b]) . R[b]  (tools/eval_ycb.py:211) with rt [B][12] = R row-major (9) then T (3)
 void launch_cloud_conv1(const float *cloud, const float *rt, const float *w, const float *bias, float *out, int out_ld,
                         int B, int N, int Npad, hipStream_t st);
+// The K = 3 / 32 / 64 head of the per-point MLPs as ONE launch (csrc/pointfeat.hip): x1 = relu(conv1(cloud)), x2 = relu(conv2(x1))
+// and / or e1 = relu(e_conv1(emb)), e2 = relu(e_conv2(e1)) (lib/network.py:53-58,152-157), written once into the [rows][ld] point-feature
+// rows at the given column offsets; the layer-pair intermediates stay in LDS (fp32 MFMA, weights staged in LDS in fragment order).
+// cloud [B][N][3] (+ optional rigid pre-transform rt [B][12], tools/eval_ycb.py:211), emb_pm [B*Npad][32]; either branch may be off
+// (null cloud / null emb).  Same sums in the same order as the layer-by-layer launches: bit-identical outputs.
+struct PointFeatParams {
+  const float *cloud = nullptr, *rt = nullptr, *emb = nullptr;
+  float *pf = nullptr;
+  int ld = 384, cx1 = 0, cx2 = 0, ce1 = 0, ce2 = 0;
+  const float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *we1 = nullptr, *be1 = nullptr, *we2 = nullptr, *be2 = nullptr;
+  int B = 0, N = 0, Npad = 0;
+};
+int launch_pointfeat(const PointFeatParams &p, hipStream_t st);
 // mean over the points of each object from the GEMM's per-wave partial column sums
 void launch_colsum_finish(const float *partial, int rows_per_obj, float *mean, int B, int C, int N, hipStream_t st);
 // y[b][g*nout + n] = act(sum_k x[b][g*x_gstride + k] * W[g*nout + n][k] + bias[..]) for a handful of rows b (one per object);

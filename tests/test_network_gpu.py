@@ -306,6 +306,48 @@ def test_a_window_with_more_than_64_crop_sizes():
         assert torch.equal(wo1, wo[i:i + 1]) and torch.equal(pose1, pose[i:i + 1]), shapes[i]
 
 
+_POINT_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from densefusion_amd import synth
+from densefusion_amd.lib.network import PoseEstimator, PoseNet, PoseRefineNet
+K, N = 21, 1000
+est, ref = PoseNet(N, K), PoseRefineNet(N, K)
+est.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.posenet_spec(K), 13).items()})
+ref.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.refiner_spec(K), 1013).items()})
+est, ref = est.cuda().eval(), ref.cuda().eval()
+out = []
+for seed, B, H, W in ((700, 3, 80, 120), (701, 2, 160, 160)):
+    b = synth.make_batch(seed, B, H, W, N, K)
+    T = lambda k: torch.from_numpy(b[k]).cuda()
+    out += [t.cpu() for t in est(T("img"), T("cloud"), T("choose"), T("obj"))]                       # PoseNet.forward: r, t, c, emb
+    out += [t.cpu() for t in PoseEstimator(est, ref).estimate(T("img"), T("cloud"), T("choose"), T("obj"), 2)]
+    out += [t.cpu() for t in ref(T("cloud"), out[-3].cuda(), T("obj"))]                               # stand-alone refiner
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_fused_point_layers_are_bit_identical_to_the_layer_by_layer_launches(tmp_path):
+    """csrc/pointfeat.hip chains conv1 -> conv2 and e_conv1 -> e_conv2 (K = 3 / 32 / 64) inside one launch with the intermediates
+    in LDS; every output element still adds the same products in the same order as the separate GEMM launches, so PoseNet's
+    outputs, the refined poses and the stand-alone refiner's outputs must not change by a bit (two child processes: the dev switch
+    DF_POINT_UNFUSED is read once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = []
+    for tag, env in (("fused", {}), ("unfused", {"DF_POINT_UNFUSED": "1"})):
+        f = str(tmp_path / f"{tag}.pt")
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, "-c", _POINT_SCRIPT, root, f], check=True, env=e, timeout=600)
+        files.append(f)
+    a, b = torch.load(files[0]), torch.load(files[1])
+    assert len(a) == len(b) == 16
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), f"output {i}: fused and layer-by-layer forms disagree, max diff {float((u.double() - v.double()).abs().max())}"
+
+
 def test_layer_taps_match_the_references_intermediates():
     """The engine's debug taps (df_net_debug_taps) against the 10 intermediates the imported reference produced for the tiny
     config (forward hooks in oracle/make_golden.py): a regression localises to a layer.  up_3 exists at the chosen pixels only."""
