@@ -25,6 +25,7 @@
 
 #include "igemm.h"
 #include "layers.h"
+#include "wino.h"
 
 namespace df {
 namespace {
@@ -672,6 +673,12 @@ struct Trainer {
   const float *flip_src = nullptr;
   struct Flip { size_t off; int O, T, I, KH, KW, Z; };
   std::vector<Flip> flips;
+  // Winograd F(4x4,3x3)-domain copies of the stride-1 3x3 trunk weights with >= 128 input channels (forward: G w G^T of the packed
+  // weights; data gradient: of the flipped ones), [36][O][I] each, rebuilt with the flips
+  struct Wino { size_t w_off, fwd, bwd; int O, I; };
+  std::map<std::string, Wino> wino;
+  float *wino_buf = nullptr;
+  size_t wino_floats = 0;
 };
 
 size_t take(Trainer &t, const std::string &name, size_t floats) {
@@ -702,6 +709,11 @@ void add_conv(Trainer &t, const std::string &key, int O, int I, int k, bool tapm
   if (tapmajor) t.flips.push_back({off, 9 * O, 1, I, 1, 1, 1});        // the low-resolution product is a 1x1 conv with 9*O outputs
   else if (as_gemm) t.flips.push_back({off, O, 1, T * Ipad, 1, 1, 1});
   else t.flips.push_back({off, O, T, Ipad, k, k, 1});
+  if (k == 3 && !tapmajor && !as_gemm && I >= 128 && I % 4 == 0 && O % 4 == 0 && key.find("feats.layer") != std::string::npos) {
+    const size_t n = (size_t)36 * O * I;
+    t.wino[key] = Trainer::Wino{off, t.wino_floats, t.wino_floats + n, O, I};
+    t.wino_floats += 2 * n;
+  }
 }
 void add_plain(Trainer &t, const std::string &key, std::initializer_list<int64_t> shp) {
   size_t n = 1;
@@ -953,7 +965,29 @@ Act *conv(Step &s, Act *x, int cin, const ConvW &cw, int cout, int k, int stride
   if (res) { p.res = res->v.d; p.res_ld = res->v.ld; }
   if (act == ACT_PRELU) p.prelu = s.p(cw.slope);
   p.splitk_ws = s.splitk; p.splitk_ws_bytes = s.splitk_bytes;
-  if (s.live()) s.fail(launch_conv(p, s.st));
+  // stride-1 3x3 trunk convolutions whose map the engine's rule sends through F(4x4,3x3) take that route here too, forward and
+  // data gradient (the weight gradient stays in the spatial domain): DF_TRAIN_NO_WINOGRAD=1 keeps the direct kernel (A/B)
+  static const bool no_wino = getenv("DF_TRAIN_NO_WINOGRAD") != nullptr;
+  const auto wit = s.t->wino.find(cw.name);
+  const bool f4 = !no_wino && wit != s.t->wino.end() && k == 3 && stride == 1 && pad == dil && cw.bias.empty() && act != ACT_PRELU &&
+                  wino_route(x->H, x->W, dil, cin, cout) == 4;
+  auto wino_pass = [=](Step &s, View in, int ci, const float *U, View out, int co, const float *rs, int rs_ld, int a) {
+    const WinoGeom g = wino_geom(x->B, x->H, x->W, dil, 4);
+    const size_t mark = s.off;
+    float *V = s.f((size_t)36 * g.T * ci), *M = s.f((size_t)36 * g.T * co);
+    if (s.live()) {
+      launch_wino_input(in.d, in.ld, 0, V, x->B, x->H, x->W, ci, dil, s.st, 0, 0, 4);
+      ConvParams q;
+      q.in = V; q.wgt = U; q.out = M;
+      q.B = (int)g.T; q.Cin = ci; q.in_ld = ci; q.Cout = co; q.out_ld = co;
+      q.zcount = 36; q.z_in_coff = g.T * ci; q.z_wgt = (long)co * ci; q.z_out_coff = g.T * co;
+      s.fail(launch_conv(q, s.st));
+      launch_wino_output(M, out.d, out.ld, 0, nullptr, rs, rs_ld, 0, a, x->B, x->H, x->W, co, dil, s.st, 0, 0, 4);
+    }
+    s.off = mark;
+  };
+  if (f4) wino_pass(s, x->v, cin, s.dry ? nullptr : s.t->wino_buf + wit->second.fwd, y->v, cout, res ? res->v.d : nullptr, res ? res->v.ld : 0, act);
+  else if (s.live()) s.fail(launch_conv(p, s.st));
   s.dbg("conv fwd", cw.name);
   Step *sp = &s;
   s.tape.push_back([=]() {
@@ -963,7 +997,8 @@ Act *conv(Step &s, Act *x, int cin, const ConvW &cw, int cout, int k, int stride
     wgrad(s, p, y->g, s.gr(cw.name, cw.woff), cw.bias.empty() ? nullptr : s.gr(cw.bias, cw.boff));
     if (need_dx) {
       const bool acc = s.grad_of(x);
-      dgrad(s, p, y->g, x->g, s.pf(cw.name, cw.woff), acc);
+      if (f4) wino_pass(s, y->g, cout, s.dry ? nullptr : s.t->wino_buf + wit->second.bwd, x->g, cin, acc ? x->g.d : nullptr, x->g.ld, ACT_NONE);
+      else dgrad(s, p, y->g, x->g, s.pf(cw.name, cw.woff), acc);
     }
     if (res) {
       if (!res->gset) { res->g = y->g; res->gset = true; }          // the residual's gradient IS this (masked) gradient: alias, no copy
@@ -987,10 +1022,16 @@ Act *slice(Step &s, Act *a, int c0, int C) {
 }
 
 int check_flips(Trainer &t, const float *P, long version, hipStream_t st) {
-  if (!t.wflip) return set_error(DF_ERR_STATE, "trainer: created without a device (no arena for the data gradients' weight copies)");
+  if (!t.wflip || (t.wino_floats && !t.wino_buf))
+    return set_error(DF_ERR_STATE, "trainer: created without a device (no arena for the data gradients' weight copies)");
   if (t.flip_version == version && t.flip_src == P && version >= 0) return DF_OK;
   for (const Trainer::Flip &f : t.flips)
     hipLaunchKernelGGL(flip_kernel, dim3(nblk((long)f.O * f.T * f.I * f.Z, 1024)), dim3(TB), 0, st, P + f.off, t.wflip + f.off, f.O, f.T, f.I, f.KH, f.KW, f.Z);
+  for (const auto &kv : t.wino) {
+    const Trainer::Wino &w = kv.second;
+    launch_wino_weight(P + w.w_off, t.wino_buf + w.fwd, w.O, w.I, st, 4);
+    launch_wino_weight(t.wflip + w.w_off, t.wino_buf + w.bwd, w.I, w.O, st, 4);       // flipped weights: [I][9][O]
+  }
   t.flip_version = version;
   t.flip_src = P;
   return check_launch("trainer: weight flips");
@@ -1463,6 +1504,7 @@ extern "C" df_trainer *df_trainer_create(int kind, int num_points, int num_obj) 
   // the data gradients' flipped / transposed weight copies; without a device (layout / workspace queries on a CPU-only host) the
   // handle still works for everything that launches nothing, and a step reports the missing arena
   if (hipMalloc(&t->wflip, t->flat * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); t->wflip = nullptr; }
+  if (t->wino_floats && hipMalloc(&t->wino_buf, t->wino_floats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); t->wino_buf = nullptr; }
   return reinterpret_cast<df_trainer *>(t);
 }
 
@@ -1470,6 +1512,7 @@ extern "C" void df_trainer_destroy(df_trainer *h) {
   if (!h) return;
   Trainer *t = as_trainer(h);
   if (t->wflip) hipFree(t->wflip);
+  if (t->wino_buf) hipFree(t->wino_buf);
   delete t;
 }
 

@@ -151,8 +151,9 @@ class PoseDataset:
     def _targets(self, obj, meta):
         pts = self.pt[obj] / 1000.0
         n, keep_n = len(pts), self.num_pt_mesh_small
-        drop = set(random.sample(range(n), n - keep_n))                    # same draw as :167-170 on Python's global stream
-        model_points = pts[[j for j in range(n) if j not in drop]]
+        keep = np.ones(n, dtype=bool)
+        keep[random.sample(range(n), n - keep_n)] = False                  # same draw as :167-170 on Python's global stream
+        model_points = pts[keep]                                           # (np.delete keeps the survivors in index order: so does this)
         target_r = np.resize(np.array(meta["cam_R_m2c"]), (3, 3))
         target = np.dot(model_points, target_r.T) + np.array(meta["cam_t_m2c"]) / 1000.0
         return torch.from_numpy(target.astype(np.float32)), torch.from_numpy(model_points.astype(np.float32))
@@ -185,6 +186,7 @@ class PoseDataset:
                 continue
             target, model_points = self._targets(h[4], h[5])
             idx = torch.tensor([self.objlist.index(h[4])], dtype=torch.int64, device=dev)
+            idx._host = [int(self.objlist.index(h[4]))]          # the trainer's losses branch on the index: spare it a device read-back
             out.append(prepared[k] + (target.to(dev), model_points.to(dev), idx))
         return out
 

@@ -110,9 +110,12 @@ class PoseDataset:
             self.num_pt, cam=cam)
         pts = self.cld[int(obj[idx])]
         keep_n = self.num_pt_mesh_large if self.refine else self.num_pt_mesh_small
-        drop = set(random.sample(range(len(pts)), len(pts) - keep_n))                 # :199-204 on Python's global stream
-        model_points = pts[[j for j in range(len(pts)) if j not in drop]]
+        keep = np.ones(len(pts), dtype=bool)
+        keep[random.sample(range(len(pts)), len(pts) - keep_n)] = False               # :199-204 on Python's global stream
+        model_points = pts[keep]
         pose = meta["poses"][:, :, idx]
         target = np.dot(model_points, pose[:, 0:3].T) + pose[:, 3:4].flatten()[None]
+        index_t = torch.tensor([int(obj[idx]) - 1], dtype=torch.int64, device=dev)
+        index_t._host = [int(obj[idx]) - 1]              # the trainer's losses branch on the index: spare it a device read-back
         return (cloud[0], choose[0], img[0], torch.from_numpy(target.astype(np.float32)).to(dev),
-                torch.from_numpy(model_points.astype(np.float32)).to(dev), torch.tensor([int(obj[idx]) - 1], dtype=torch.int64, device=dev))
+                torch.from_numpy(model_points.astype(np.float32)).to(dev), index_t)

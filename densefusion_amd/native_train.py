@@ -31,6 +31,8 @@ class NativeTrainer:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("densefusion_amd needs a GPU device (no CPU path)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         L = _lib.lib()
         with _lib.device_guard(self.device):
             self._h = L.df_trainer_create(self.kind, self.num_points, self.num_obj)
