@@ -624,6 +624,29 @@ __global__ __launch_bounds__(TB) void flip_kernel(const float *__restrict__ w, f
   }
 }
 
+// every flip of a trainer in ONE launch: segment table in device memory (begin = first element of the segment in the launch's index space)
+struct FlipSeg { long off, begin; int O, T, I, KH, KW, Z; };
+__global__ __launch_bounds__(TB) void flip_all_kernel(const float *__restrict__ P, float *__restrict__ wf, const FlipSeg *__restrict__ segs, int nseg,
+                                                      long total) {
+  GRID_STRIDE(g, total) {
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {                               // last segment whose begin <= g
+      const int mid = (lo + hi + 1) >> 1;
+      if (segs[mid].begin <= g) lo = mid; else hi = mid - 1;
+    }
+    const FlipSeg sg = segs[lo];
+    const long i = g - sg.begin, per = (long)sg.O * sg.T * sg.I;
+    const long z = i / per, l = i - z * per;
+    const int n = (int)(l % sg.O);
+    const long r = l / sg.O;
+    const int t = (int)(r % sg.T);
+    const long c = r / sg.T;
+    const int ky = t / sg.KW, kx = t - ky * sg.KW;
+    const int tf = (sg.KH - 1 - ky) * sg.KW + (sg.KW - 1 - kx);
+    wf[sg.off + i] = P[sg.off + z * per + ((size_t)n * sg.T + tf) * sg.I + c];
+  }
+}
+
 // layout conversion between the reference's state-dict tensors and the flat kernel layout
 //   mode 0: OIHW [O][I][T] <-> O(T)Ipad          mode 1: OIHW (T = 9) <-> tap-major [9][O][I]          (dir 0: pack, 1: unpack)
 __global__ __launch_bounds__(TB) void relayout_kernel(const float *__restrict__ src, float *__restrict__ dst, int O, int I, int T, int Ipad, int mode,
@@ -679,6 +702,8 @@ struct Trainer {
   std::map<std::string, Wino> wino;
   float *wino_buf = nullptr;
   size_t wino_floats = 0;
+  FlipSeg *flip_tab = nullptr;     // device copy of `flips` for the one-launch flip
+  long flip_total = 0;
 };
 
 size_t take(Trainer &t, const std::string &name, size_t floats) {
@@ -1025,8 +1050,11 @@ int check_flips(Trainer &t, const float *P, long version, hipStream_t st) {
   if (!t.wflip || (t.wino_floats && !t.wino_buf))
     return set_error(DF_ERR_STATE, "trainer: created without a device (no arena for the data gradients' weight copies)");
   if (t.flip_version == version && t.flip_src == P && version >= 0) return DF_OK;
-  for (const Trainer::Flip &f : t.flips)
-    hipLaunchKernelGGL(flip_kernel, dim3(nblk((long)f.O * f.T * f.I * f.Z, 1024)), dim3(TB), 0, st, P + f.off, t.wflip + f.off, f.O, f.T, f.I, f.KH, f.KW, f.Z);
+  if (t.flip_tab)
+    hipLaunchKernelGGL(flip_all_kernel, dim3(nblk(t.flip_total, 8192)), dim3(TB), 0, st, P, t.wflip, t.flip_tab, (int)t.flips.size(), t.flip_total);
+  else
+    for (const Trainer::Flip &f : t.flips)
+      hipLaunchKernelGGL(flip_kernel, dim3(nblk((long)f.O * f.T * f.I * f.Z, 1024)), dim3(TB), 0, st, P + f.off, t.wflip + f.off, f.O, f.T, f.I, f.KH, f.KW, f.Z);
   for (const auto &kv : t.wino) {
     const Trainer::Wino &w = kv.second;
     launch_wino_weight(P + w.w_off, t.wino_buf + w.fwd, w.O, w.I, st, 4);
@@ -1505,6 +1533,18 @@ extern "C" df_trainer *df_trainer_create(int kind, int num_points, int num_obj) 
   // handle still works for everything that launches nothing, and a step reports the missing arena
   if (hipMalloc(&t->wflip, t->flat * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); t->wflip = nullptr; }
   if (t->wino_floats && hipMalloc(&t->wino_buf, t->wino_floats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); t->wino_buf = nullptr; }
+  {
+    std::vector<FlipSeg> tab;
+    long begin = 0;
+    for (const Trainer::Flip &f : t->flips) {
+      tab.push_back(FlipSeg{(long)f.off, begin, f.O, f.T, f.I, f.KH, f.KW, f.Z});
+      begin += (long)f.O * f.T * f.I * f.Z;
+    }
+    t->flip_total = begin;
+    if (t->wflip && hipMalloc(&t->flip_tab, tab.size() * sizeof(FlipSeg)) == hipSuccess)
+      hipMemcpy(t->flip_tab, tab.data(), tab.size() * sizeof(FlipSeg), hipMemcpyHostToDevice);
+    else { (void)hipGetLastError(); t->flip_tab = nullptr; }
+  }
   return reinterpret_cast<df_trainer *>(t);
 }
 
@@ -1513,6 +1553,7 @@ extern "C" void df_trainer_destroy(df_trainer *h) {
   Trainer *t = as_trainer(h);
   if (t->wflip) hipFree(t->wflip);
   if (t->wino_buf) hipFree(t->wino_buf);
+  if (t->flip_tab) hipFree(t->flip_tab);
   delete t;
 }
 

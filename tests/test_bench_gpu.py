@@ -30,7 +30,7 @@ def test_bench_json_contract():
     assert abs(d["value"] - poses / (d["ms_per_step"] * d["steps"] / 1e3)) <= 0.01 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and 0 < r["useful_frac"] <= r["frac"]
-    assert 0 < r["whole_step_useful_frac"] <= r["whole_step_frac"] < r["frac"]
+    assert 0 < r["whole_step_useful_frac"] <= r["whole_step_frac"] < 1     # (wall time with 4 steps in flight; at this tiny batch it can beat the serial GEMM sum)
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_us"] * 1e3) <= 0.02 * r["achieved"]     # GFLOP / us = PFLOP/s
     assert r["traffic"] is None                       # the committed PMC profile is for the default batch only
