@@ -253,3 +253,33 @@ def test_lanes_give_the_single_lane_gradients_and_repeat_bit_for_bit():
     lanes.close()
     assert torch.equal(runs[0], runs[1])
     _close(runs[0], g1, 5e-4, "lane-summed gradient")
+
+
+def test_native_step_with_repeated_pixels_and_a_repeated_object():
+    """Corners of the backward pass: `choose` wrap-padded from a few mask pixels (datasets/ycb/dataset.py:156-163: every pixel is
+    chosen several times, so the chosen-pixel adjoints add several points into one pixel) and two frames of the SAME object in one
+    pass (their last-layer gradients land in the same rows) -- against torch CPU autograd through the oracle, frame by frame."""
+    K, N, H, W, M = 3, 64, 40, 40, 60
+    sd = synth.make_state_dict(synth.posenet_spec(K), 23)
+    objs = [synth.make_object(800 + i, H, W, N, K, num_points_mesh=M) for i in range(2)]
+    rng = np.random.default_rng(5)
+    for o in objs:
+        o["obj"][0] = 2
+        few = np.sort(rng.choice(H * W, size=11, replace=False))
+        o["choose"] = np.resize(few, N).reshape(1, N).astype(np.int64)              # np.pad(..., 'wrap') of 11 pixels
+    psd = {k: torch.from_numpy(v).clone().requires_grad_() for k, v in sd.items()}
+    total = 0
+    for o in objs:
+        T = lambda k: torch.from_numpy(o[k])[None]
+        idx = torch.tensor([[2]])
+        r, t, c, _ = dfnet.posenet_forward(psd, T("img"), T("cloud"), torch.from_numpy(o["choose"]), idx)
+        total = total + loss_ref.loss_calculation(r, t, c, T("target"), T("model_points"), idx, T("cloud"), 0.015, False, M, [2])[0]
+    total.backward()
+    tr = _trainer("posenet", N, K, sd)
+    f = _frames(objs)
+    out = tr.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], [True, True], 0.015, dropout=False)
+    _close(out["loss"].sum(), total, 1e-4, "loss")
+    for key, g in tr.grad_dict().items():
+        if "classifier" in key:
+            continue
+        _close(g, psd[key].grad, 3e-3, key)
