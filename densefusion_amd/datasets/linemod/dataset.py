@@ -192,3 +192,33 @@ class PoseDataset:
 
     def __getitem__(self, index):
         return self.batch([index])[0]
+
+    # -- the same fetch cut in two for train_utils.Prefetcher(processes=...): worker processes decode, the trainer's process uploads --
+    def host_item(self, index):
+        """CPU half of ``__getitem__`` (never touches the device: runs in the loader's worker processes like the reference's
+        DataLoader workers, tools/train.py:106): the decoded frame, the snapped box, the number of mask pixels in it and the
+        sampled model / target points, as host tensors."""
+        rgb, depth, lab2d, box, obj, meta = self._host_frame(index)
+        rmin, rmax, cmin, cmax = box
+        count = int(np.count_nonzero((depth[rmin:rmax, cmin:cmax] != 0) & (lab2d[rmin:rmax, cmin:cmax] == 255)))
+        for _ in range(3):
+            random.uniform(-self.noise_trans, self.noise_trans)            # add_t is drawn even when unused (:129)
+        target, model_points = self._targets(obj, meta)
+        return (torch.from_numpy(np.array(rgb)), torch.from_numpy(depth.view(np.int16)), torch.from_numpy(lab2d),
+                torch.tensor([rmin, rmax, cmin, cmax, count, self.objlist.index(obj)], dtype=torch.int64), target, model_points)
+
+    def device_item(self, index, host):
+        """Device half: uploads + one preparation launch on the current stream, no read-back.  Same 6-tuple as ``__getitem__``."""
+        rgb, depth, lab2d, info, target, model_points = host
+        rmin, rmax, cmin, cmax, count, oi = (int(v) for v in info.tolist())
+        if count == 0:
+            cc = torch.LongTensor([0])
+            return (cc, cc, cc, cc, cc, cc)
+        dev = self.device
+        up = lambda t: t.to(dev, non_blocking=True)            # asynchronous when the loader pinned `t`, staged otherwise
+        img, cloud, choose, _ = pp.preprocess_objects(up(rgb)[None], up(depth)[None], up(lab2d)[None],
+                                                      [(0, 255, (rmin, rmax, cmin, cmax), (self.seed * 1000003 + int(index)) & 0xFFFFFFFF)],
+                                                      self.num, cam=pp.LINEMOD_CAM)
+        idx = torch.tensor([oi], dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
+        idx._host = [oi]
+        return (cloud[0], choose[0], img[0], up(target), up(model_points), idx)

@@ -85,7 +85,10 @@ class PoseDataset:
     def get_num_points_mesh(self):
         return self.num_pt_mesh_large if self.refine else self.num_pt_mesh_small
 
-    def __getitem__(self, index):
+    def host_item(self, index):
+        """CPU half of ``__getitem__`` (never touches the device: runs in the worker processes of
+        ``train_utils.Prefetcher(processes=...)`` like the reference's DataLoader workers, tools/train.py:106): decoded frame, the
+        object drawn from it, its box, camera, and the sampled model / target points, as host tensors."""
         name = self.list[index]
         if name[:8] == "data_syn":
             raise NotImplementedError("synthetic frames (data_syn) need the reference's augmentation pipeline; not available in this build")
@@ -103,11 +106,6 @@ class PoseDataset:
         box = get_bbox(mask_label)
         for _ in range(3):
             random.uniform(-self.noise_trans, self.noise_trans)        # add_t is drawn even when unused (:171)
-        dev = self.device
-        img, cloud, choose, _count = pp.preprocess_objects(
-            torch.from_numpy(rgb[None]).to(dev), torch.from_numpy(depth[None].view(np.int16)).to(dev),
-            torch.from_numpy(label[None].astype(np.int32)).to(dev), [(0, int(obj[idx]), box, (self.seed * 1000003 + index) & 0xFFFFFFFF)],
-            self.num_pt, cam=cam)
         pts = self.cld[int(obj[idx])]
         keep_n = self.num_pt_mesh_large if self.refine else self.num_pt_mesh_small
         keep = np.ones(len(pts), dtype=bool)
@@ -115,7 +113,24 @@ class PoseDataset:
         model_points = pts[keep]
         pose = meta["poses"][:, :, idx]
         target = np.dot(model_points, pose[:, 0:3].T) + pose[:, 3:4].flatten()[None]
-        index_t = torch.tensor([int(obj[idx]) - 1], dtype=torch.int64, device=dev)
-        index_t._host = [int(obj[idx]) - 1]              # the trainer's losses branch on the index: spare it a device read-back
-        return (cloud[0], choose[0], img[0], torch.from_numpy(target.astype(np.float32)).to(dev),
-                torch.from_numpy(model_points.astype(np.float32)).to(dev), index_t)
+        return (torch.from_numpy(rgb), torch.from_numpy(depth.view(np.int16)), torch.from_numpy(label.astype(np.int32)),
+                torch.tensor(list(box) + [int(obj[idx])], dtype=torch.int64),
+                torch.tensor([cam[k] for k in ("cx", "cy", "fx", "fy", "scale")], dtype=torch.float64),
+                torch.from_numpy(target.astype(np.float32)), torch.from_numpy(model_points.astype(np.float32)))
+
+    def device_item(self, index, host):
+        """Device half: uploads + one preparation launch on the current stream.  The 6-tuple of ``__getitem__``."""
+        rgb, depth, label, info, camv, target, model_points = host
+        rmin, rmax, cmin, cmax, cls = (int(v) for v in info.tolist())
+        cam = dict(zip(("cx", "cy", "fx", "fy", "scale"), camv.tolist()))
+        dev = self.device
+        up = lambda t: t.to(dev, non_blocking=True)            # asynchronous when the loader pinned `t`, staged otherwise
+        img, cloud, choose, _count = pp.preprocess_objects(up(rgb)[None], up(depth)[None], up(label)[None],
+                                                           [(0, cls, (rmin, rmax, cmin, cmax), (self.seed * 1000003 + int(index)) & 0xFFFFFFFF)],
+                                                           self.num_pt, cam=cam)
+        index_t = torch.tensor([cls - 1], dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
+        index_t._host = [cls - 1]                        # the trainer's losses branch on the index: spare it a device read-back
+        return (cloud[0], choose[0], img[0], up(target), up(model_points), index_t)
+
+    def __getitem__(self, index):
+        return self.device_item(index, self.host_item(index))

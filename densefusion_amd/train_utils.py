@@ -105,21 +105,74 @@ def host_index(idx):
     return int(idx.reshape(-1)[0].item())
 
 
+class _HostHalf:
+    """What the loader's worker processes see of a dataset: ``host_item`` only (the CPU half of a fetch)."""
+
+    def __init__(self, dataset):
+        self.dataset = dataset
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitem__(self, i):
+        return self.dataset.host_item(int(i))
+
+
+class _Order:
+    """A sampler whose index list can be replaced between epochs (the worker processes persist)."""
+
+    def __init__(self, order):
+        self.order = list(order)
+
+    def __iter__(self):
+        return iter(list(self.order))
+
+    def __len__(self):
+        return len(self.order)
+
+
 class Prefetcher:
-    """Bounded look-ahead over ``dataset[i] for i in order`` (the job of the reference's 10-worker DataLoader, tools/train.py:106):
-    `workers` threads fetch frames, pin the host tensors and upload them on a copy stream, at most `depth` frames ahead of the
-    consumer; iteration yields the frames IN ORDER as tuples of device tensors whose upload the consumer's stream has been made
-    to wait for.  Items that are not tuples of tensors (a loader's sentinel) and tensors that already live on the device pass
-    through.  ``workers = 0``: fetch synchronously in the caller's thread (same results)."""
+    """Bounded look-ahead over ``dataset[i] for i in order`` (the job of the reference's 10-worker DataLoader, tools/train.py:106).
+    Iteration yields the frames IN ORDER as tuples of device tensors whose upload the consumer's current stream has been made to
+    wait for (and which that stream is recorded as a user of, so the allocator does not hand their memory to a later upload while
+    the consumer's kernels are still queued).  Items that are not tuples of tensors (a loader's sentinel) and tensors that already
+    live on the device pass through.
 
-    def __init__(self, dataset, order, device, workers=4, depth=None):
-        self.dataset, self.order, self.device = dataset, [int(i) for i in order], torch.device(device)
+    * ``workers`` threads fetch ``dataset[i]``, pin host tensors and upload them on a copy stream, at most ``depth`` frames ahead.
+      ``workers = 0``: fetch synchronously in the caller's thread (same results).
+    * ``processes`` > 0 and a dataset that splits its fetch (``host_item(i)`` -> host tensors, ``device_item(i, host)`` -> the item):
+      the CPU half -- PNG decoding, the Python-level sampling -- runs in that many worker PROCESSES (torch's DataLoader, "spawn"
+      context: they never touch the device; shared-memory + pinned hand-over), one feeder thread runs the device half on the copy stream.  Python
+      threads share one interpreter lock: the disk datasets decode ~4x faster on threads and ~N x on N processes.
+      The worker processes persist over ``set_order()`` / repeated iteration until ``close()``."""
+
+    def __init__(self, dataset, order, device, workers=4, depth=None, processes=0):
+        self.dataset, self.device = dataset, torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self._order = _Order(int(i) for i in order)
         self.workers = max(0, int(workers))
-        self.depth = int(depth) if depth else max(2, 2 * self.workers)
+        self.processes = max(0, int(processes)) if hasattr(dataset, "host_item") else 0
+        self.depth = int(depth) if depth else max(2, 2 * max(self.workers, self.processes))
         self.copy_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        self._loader = None
 
-    def _fetch(self, i):
-        item = self.dataset[i]
+    @property
+    def order(self):
+        return self._order.order
+
+    def set_order(self, order):
+        self._order.order = [int(i) for i in order]
+        return self
+
+    def close(self):
+        if self._loader is not None:
+            it = getattr(self._loader, "_iterator", None)
+            if it is not None and hasattr(it, "_shutdown_workers"):
+                it._shutdown_workers()
+            self._loader = None
+
+    def _upload(self, item):
         if self.copy_stream is None or not isinstance(item, (tuple, list)):
             return item, None
         with torch.cuda.stream(self.copy_stream):
@@ -135,21 +188,38 @@ class Prefetcher:
             ev.record(self.copy_stream)
         return tuple(out), ev
 
+    def _fetch(self, i):
+        if self.copy_stream is None:
+            return self.dataset[i], None
+        with torch.cuda.stream(self.copy_stream):              # a dataset that prepares on the device does so on the copy stream
+            item = self.dataset[i]
+        return self._upload(item)
+
+    def _hand_over(self, item, ev):
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for t in item:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur)
+        return item
+
     def __len__(self):
-        return len(self.order)
+        return len(self._order)
 
     def __iter__(self):
+        if self.processes:
+            yield from self._iter_processes()
+            return
+        order = list(self._order.order)
         if self.workers == 0:
-            for i in self.order:
-                item, ev = self._fetch(i)
-                if ev is not None:
-                    torch.cuda.current_stream(self.device).wait_event(ev)
-                yield item
+            for i in order:
+                yield self._hand_over(*self._fetch(i))
             return
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="df-prefetch") as pool:
-            pending, it = deque(), iter(self.order)
+            pending, it = deque(), iter(order)
             for i in it:
                 pending.append(pool.submit(self._fetch, i))
                 if len(pending) >= self.depth:
@@ -159,6 +229,56 @@ class Prefetcher:
                 nxt = next(it, None)
                 if nxt is not None:
                     pending.append(pool.submit(self._fetch, nxt))
-                if ev is not None:
-                    torch.cuda.current_stream(self.device).wait_event(ev)
-                yield item
+                yield self._hand_over(item, ev)
+
+    def _iter_processes(self):
+        import queue
+        import threading
+        from torch.utils.data import DataLoader
+        if self._loader is None:
+            self._loader = DataLoader(_HostHalf(self.dataset), batch_size=None, sampler=self._order, num_workers=self.processes,
+                                      multiprocessing_context="spawn", pin_memory=self.copy_stream is not None, prefetch_factor=2,
+                                      persistent_workers=True)
+            import warnings                  # torch's own pin thread passes the deprecated `device` argument, once per tensor
+            warnings.filterwarnings("ignore", message=r".*(pin_memory|is_pinned).*deprecated.*")
+        order = list(self._order.order)
+        q, stop = queue.Queue(maxsize=self.depth), threading.Event()
+
+        def put(x):
+            while not stop.is_set():
+                try:
+                    q.put(x, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def feed():
+            try:
+                if self.copy_stream is not None:
+                    torch.cuda.set_device(self.device)
+                for i, host in zip(order, self._loader):
+                    if self.copy_stream is not None:
+                        with torch.cuda.stream(self.copy_stream):
+                            item = self.dataset.device_item(i, host)
+                    else:
+                        item = self.dataset.device_item(i, host)
+                    if not put(self._upload(item)):
+                        return
+                put(None)
+            except BaseException as e:                          # surfaces in the consumer's thread
+                put(e)
+
+        th = threading.Thread(target=feed, name="df-feed", daemon=True)
+        th.start()
+        try:
+            while True:
+                got = q.get()
+                if got is None:
+                    break
+                if isinstance(got, BaseException):
+                    raise got
+                yield self._hand_over(*got)
+        finally:
+            stop.set()
+            th.join()

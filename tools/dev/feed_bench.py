@@ -1,6 +1,7 @@
 """Dev tool: does the trainer's data feed keep up?  Frames/s of the native PoseNet training loop on a fabricated LineMOD tree (PNG
-decoding, gt.yml, .ply models: densefusion_amd.datasets.linemod) fed through train_utils.Prefetcher with 0 / 4 / 8 worker threads,
-against the same loop over frames that already sit in device memory.  usage: feed_bench.py TREE_ROOT"""
+decoding, gt.yml, .ply models: densefusion_amd.datasets.linemod) fed through train_utils.Prefetcher with 0 / 4 / 8 worker threads
+and with 8 / 12 worker processes, against the same loop over frames that already sit in device memory.
+usage: feed_bench.py TREE_ROOT"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -8,7 +9,7 @@ from densefusion_amd import synth, train_utils
 from densefusion_amd.native_train import Lanes, NativeTrainer
 
 
-def run(root, workers_list=(0, 4, 8), frames=96, lanes_n=4, out=print):
+def run(root, workers_list=(0, 4, 8), frames=96, lanes_n=4, out=print, processes_list=(8, 12)):
     from densefusion_amd.datasets.linemod.dataset import PoseDataset
     dev = torch.device("cuda")
     ds = PoseDataset("train", 500, False, root, 0.0, False)
@@ -44,6 +45,13 @@ def run(root, workers_list=(0, 4, 8), frames=96, lanes_n=4, out=print):
         t0 = time.perf_counter()
         n = loop(train_utils.Prefetcher(ds, order, dev, workers=w))
         res[f"workers_{w}_frames_per_s"] = round(n / (time.perf_counter() - t0), 1)
+    for w in processes_list:
+        pf = train_utils.Prefetcher(ds, order, dev, workers=0, processes=w)
+        loop(pf.set_order(order[:16]))           # the worker processes start (imports) outside the timed pass, as in a long run
+        t0 = time.perf_counter()
+        n = loop(pf.set_order(order))
+        res[f"processes_{w}_frames_per_s"] = round(n / (time.perf_counter() - t0), 1)
+        pf.close()
     lanes.close()
     out(res)
     return res

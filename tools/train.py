@@ -70,8 +70,11 @@ def build_parser():
     ap.add_argument("--frames_per_pass", type=int, default=1,
                     help="frames of equal crop size, out of one accumulation window, that share a forward/backward pass (1 = the "
                          "reference's bs = 1 passes; the gradients of a window are the same either way)")
-    ap.add_argument("--workers", type=int, default=4, help="prefetch threads: frames are fetched, pinned and uploaded on a copy stream "
+    ap.add_argument("--workers", type=int, default=4, help="prefetch workers: frames are fetched, pinned and uploaded on a copy stream "
                                                          "ahead of the step (0 = fetch in the training loop)")
+    ap.add_argument("--feed", type=str, default="processes", choices=["processes", "threads"],
+                    help="processes: the disk datasets decode in --workers worker processes (the reference's DataLoader workers) and the "
+                         "trainer's process only uploads; threads: --workers threads of the trainer's process do both (always for the synthetic set)")
     ap.add_argument("--lanes", type=int, default=4,
                     help="PoseNet phase, native step: passes of one accumulation window run on this many concurrent lanes (own HIP stream, "
                          "host thread, workspace and gradient buffer each; gradients summed in lane order): bs = 1 passes fill a fraction "
@@ -289,6 +292,21 @@ def main(argv=None):
         total.backward()
         return [float(d.detach()) for d in dists]
 
+    feeds = {}
+
+    def feed(ds, order):
+        """The look-ahead over `ds` in `order`; one Prefetcher per dataset, so its worker processes persist over the epochs."""
+        pf = feeds.get(id(ds))
+        if pf is None:
+            pf = feeds[id(ds)] = train_utils.Prefetcher(ds, order, dev, workers=opt.workers,
+                                                        processes=opt.workers if opt.feed == "processes" else 0)
+        return pf.set_order(order)
+
+    def close_feeds():
+        for pf in feeds.values():
+            pf.close()
+        feeds.clear()
+
     best_test = np.inf
     st_time = time.time()
     frames_seen = 0
@@ -312,7 +330,7 @@ def main(argv=None):
                                 for rep in range(opt.repeat_epoch)]) if steps else np.zeros(0, dtype=np.int64)
         window, slots = [], 0
         window_dis = torch.zeros((), device=dev)
-        for item in train_utils.Prefetcher(dataset, order, dev, workers=opt.workers):
+        for item in feed(dataset, order):
             data = to_dev(item)
             slots += 1
             if data is not None:
@@ -356,7 +374,7 @@ def main(argv=None):
         estimator.eval(); refiner.eval()
         test_dis, test_count = 0.0, 0
         with torch.no_grad():
-            for item in train_utils.Prefetcher(test_dataset, range(rank, len(test_dataset), world), dev, workers=opt.workers):
+            for item in feed(test_dataset, range(rank, len(test_dataset), world)):
                 data = to_dev(item)
                 if data is None:
                     continue
@@ -393,9 +411,11 @@ def main(argv=None):
             opt.batch_size = max(1, int(opt.batch_size / opt.iteration))
             flat, optimizer = optimizer_for(refiner)
             if opt.dataset != "synthetic":
+                close_feeds()
                 dataset, test_dataset = make_datasets(opt)
                 opt.sym_list, opt.num_points_mesh = dataset.get_sym_list(), dataset.get_num_points_mesh()
                 criterion, criterion_refine = Loss(opt.num_points_mesh, opt.sym_list), Loss_refine(opt.num_points_mesh, opt.sym_list)
+    close_feeds()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
