@@ -101,28 +101,7 @@ __global__ __launch_bounds__(TB) void add2d_kernel(float *__restrict__ dst, int 
   }
 }
 
-// AdaptiveAvgPool2d(s), lib/pspnet.py:16: bin i covers [floor(i*H/s), ceil((i+1)*H/s)); x is a [B*H*W][C] view
-__global__ __launch_bounds__(TB) void pool_fwd_kernel(const float *__restrict__ x, int x_ld, float *__restrict__ y, int B, int H, int W, int C4, int s) {
-  GRID_STRIDE(i, (long)B * s * s * C4) {
-    const int c = (int)(i % C4) * 4;
-    long r = i / C4;
-    const int bj = (int)(r % s); r /= s;
-    const int bi = (int)(r % s);
-    const int b = (int)(r / s);
-    const int y0 = (bi * H) / s, y1 = ((bi + 1) * H + s - 1) / s, x0 = (bj * W) / s, x1 = ((bj + 1) * W + s - 1) / s;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int yy = y0; yy < y1; ++yy)
-      for (int xx = x0; xx < x1; ++xx) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((long)(b * H + yy) * W + xx) * x_ld + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += v[e];
-      }
-    const float cnt = (float)((y1 - y0) * (x1 - x0));
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] /= cnt;
-    reinterpret_cast<f32x4 *>(y)[i] = acc;
-  }
-}
+// AdaptiveAvgPool2d(s) backward, lib/pspnet.py:16: bin i covers [floor(i*H/s), ceil((i+1)*H/s)); dx is a [B*H*W][C] view
 __global__ __launch_bounds__(TB) void pool_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx, int dx_ld, int B, int H, int W, int C4,
                                                       int s, int accumulate) {
   GRID_STRIDE(i, (long)B * H * W * C4) {
@@ -1174,10 +1153,12 @@ void posenet_step(Step &s, const PoseNetIO &io) {
   const int h = x->H, w = x->W;
   // PSP module (lib/pspnet.py:20-24): pool -> 1x1 conv -> bilinear (align_corners=False) into the concat slots
   Act *feat = x;           // == cat[:, 2048:2560]
+  // all four pyramid levels in one launch (the inference engine's kernel: level i is the compact [B][sz][sz][512] block i of `pyr`)
+  float *pyr = s.f((size_t)4 * B * 36 * 512);
+  if (s.live()) launch_psp_pool(feat->v.d, feat->v.ld, 0, pyr, B, h, w, 512, s.st);
   for (int i = 0; i < 4; ++i) {
     const int sz = i == 0 ? 1 : i == 1 ? 2 : i == 2 ? 3 : 6;
-    Act *pooled = s.act(B, sz, sz, 512);
-    if (s.live()) hipLaunchKernelGGL(pool_fwd_kernel, dim3(nblk((long)B * sz * sz * 128)), dim3(TB), 0, s.st, feat->v.d, feat->v.ld, pooled->v.d, B, h, w, 128, sz);
+    Act *pooled = s.act(B, sz, sz, 512, pyr + (size_t)i * B * 36 * 512, 512);
     s.tape.push_back([=]() {
       Step &s = *sp;
       const bool acc = s.grad_of(feat);
