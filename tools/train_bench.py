@@ -18,7 +18,7 @@ def main():
     crops = [(160, 160)] if os.environ.get("DF_TB_ONE_SIZE") else [(80, 80), (120, 120), (120, 160), (160, 160), (160, 200), (200, 240), (240, 320)]
     sym_list = [12, 15, 18, 19, 20]
     groups = []
-    for gi in range(16 // P if P > 1 else 16):
+    for gi in range(max(16 // P, len(crops)) if P > 1 else 16):
         H, W = crops[gi % len(crops)]
         objs = []
         for j in range(P):
