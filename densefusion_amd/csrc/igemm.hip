@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const ConvParams p, floa
 
 // ------------------------------------------------------------------------------------------------
 // Weight gradient, large shapes: 128 (n) x 128 (k) output tile, 4 waves x (2 x 2) 32x32 accumulators, pixel chunks of 32
-// through a double-buffered LDS tile with the next chunk's global loads in flight (the forward kernel's pipeline, with the
+// through one LDS tile with the next chunk's global loads in flight in registers (the forward kernel's pipeline, with the
 // contraction over the pixel axis).  Both operands are staged as [pixel][channel] rows (16-byte global loads along the
 // contiguous channel axis, ds_write_b128); the MFMA takes two pixels per step with lanes along n (A operand, dY) and along k
 // (B operand, the im2col view of x): fragment reads are ds_read(2)_b32 over 32 consecutive floats of a row.  The n side of
@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_v2_kernel(const ConvParams p, f
   constexpr int OPY = RM * LDY, OPA = RM * LDA;      // operand tiles (floats)
   constexpr int NI = TN_ / 64;                       // 32x32 accumulators per wave along n
   constexpr int VY = TN_ / 4, RPY = 256 / VY, PY = RM / RPY;      // dY loader: vectors per row, rows per pass, passes
-  extern __shared__ __attribute__((aligned(16))) float smem[];      // [2 buffers][dY tile | A tile]
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // [dY tile | A tile]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
@@ -1095,8 +1095,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_v2_kernel(const ConvParams p, f
       ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, o, 0, 0);
     }
   };
-  auto write_lds = [&](int buf) {
-    float *sY = smem + buf * (OPY + OPA), *sA = sY + OPY;
+  auto write_lds = [&]() {
+    float *sY = smem, *sA = sY + OPY;
 #pragma unroll
     for (int i = 0; i < PY; ++i) *reinterpret_cast<u32x4 *>(sY + (yrow + RPY * i) * LDY + yvec * 4) = ry[i];
 #pragma unroll
@@ -1113,18 +1113,14 @@ __global__ __launch_bounds__(256) void wgrad_f32_v2_kernel(const ConvParams p, f
   const int fy = lh * LDY + wn * (TN_ / 2) + li, fa = OPY + lh * LDA + wk * 64 + li;
   if (nt > 0) {
     issue_loads(0);
-    write_lds(0);
+    write_lds();
     issue_loads(1);
   }
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    const float *base = smem + (t & 1) * (OPY + OPA);
+    const float *base = smem;
 #pragma unroll
     for (int s = 0; s < RM / 2; ++s) {
-      if (s == RM / 4) {               // mid-tile: hand the next chunk to the idle buffer, start the one after
-        write_lds((t & 1) ^ 1);
-        issue_loads(t + 2);
-      }
       float a[NI];
 #pragma unroll
       for (int i = 0; i < NI; ++i) a[i] = base[fy + s * 2 * LDY + i * 32];
@@ -1134,6 +1130,13 @@ __global__ __launch_bounds__(256) void wgrad_f32_v2_kernel(const ConvParams p, f
         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b0, acc[i][0], 0, 0, 0);
         acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b1, acc[i][1], 0, 0, 0);
       }
+    }
+    // ONE LDS tile per workgroup (4 workgroups per CU instead of the 2 a double buffer allows: the other three cover this hand-over);
+    // the next chunk has been in flight in registers for the whole tile
+    __syncthreads();
+    if (t + 1 < nt) {
+      write_lds();
+      issue_loads(t + 2);
     }
     __syncthreads();
   }
@@ -1396,8 +1399,8 @@ WgradPlan wgrad_plan(const ConvParams &p) {
   w.big = p.Cout >= 64 && K >= 128;
   const int tn = w.big && p.Cout >= 128 ? 128 : 64, tk = w.big ? 128 : 64;
   w.tiles = ((p.Cout + tn - 1) / tn) * ((K + tk - 1) / tk);
-  // split the pixel range so that ~1024 workgroups are in flight, each with at least 256 pixels
-  int split = (1024 + w.tiles - 1) / w.tiles;
+  // split the pixel range so that one round of workgroups (4 per CU: 1024) is in flight, each with at least 256 pixels
+  int split = 1024 / w.tiles;
   const int max_split = (M + 255) / 256;
   if (split > max_split) split = max_split;
   if (split > 256) split = 256;          // (the partial slices are re-read by the reduction)
@@ -1437,7 +1440,7 @@ int launch_wgrad(const ConvParams &p0, float *dw, float *db, void *ws, size_t ws
     static bool attr_done[64] = {};
     int dev = 0;
     hipGetDevice(&dev);
-    constexpr size_t lds128 = (size_t)2 * 32 * (132 + 132) * 4, lds64 = (size_t)2 * 32 * (68 + 132) * 4;
+    constexpr size_t lds128 = (size_t)32 * (132 + 132) * 4, lds64 = (size_t)32 * (68 + 132) * 4;
     if (dev >= 0 && dev < 64 && !attr_done[dev]) {
       hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_f32_v2_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
       attr_done[dev] = true;
