@@ -170,4 +170,5 @@ def test_prefetch_threads_feed_the_native_trainer(tree):
     res = feed_bench.run(tree, workers_list=(0, 8), frames=192, out=lambda r: None, processes_list=(8,))
     assert res["workers_8_frames_per_s"] > 1.5 * res["workers_0_frames_per_s"], res
     assert res["workers_8_frames_per_s"] > 0.4 * res["resident_frames_per_s"], res
-    assert res["processes_8_frames_per_s"] > 0.6 * res["resident_frames_per_s"], res         # worker processes (0.89 measured on 640 frames)
+    assert res["processes_8_frames_per_s"] > 2.0 * res["workers_0_frames_per_s"], res        # worker processes (0.89 of resident on 640 frames)
+    assert res["processes_8_frames_per_s"] > 0.4 * res["resident_frames_per_s"], res
