@@ -618,7 +618,7 @@ def main():
             self.groups = make_groups(buckets, args.groups, device)
             self.pe = [PoseEstimator(est, ref) for _ in self.groups]          # one workspace per group (they may run concurrently)
             self.gstreams = None if (args.no_streams or len(self.groups) == 1) else [torch.cuda.Stream() for _ in self.groups]
-            self.stream = torch.cuda.Stream()
+            self.stream = inst_streams.pop() if inst_streams else torch.cuda.Stream()
             self.graph = None
             run_step(self.pe, self.groups)                                     # eager pass: uploads weights, sizes the workspaces
             torch.cuda.synchronize()
@@ -650,6 +650,9 @@ def main():
             mine = torch.cat([g["out"][1] for g in self.groups])
             dist.all_gather(gathered, mine if args.backend == "nccl" else mine.cpu())
 
+    from densefusion_amd.streams import concurrent_streams
+    # the steps in flight overlap only if their streams sit on different hardware queues: tested, not assumed (streams.py)
+    inst_streams = [] if os.environ.get("DF_BENCH_PLAIN_STREAMS") else concurrent_streams(device, max(1, args.inflight))
     insts = [Instance() for _ in range(max(1, args.inflight))]
     groups, pe = insts[0].groups, insts[0].pe
     graph, streams = insts[0].graph, insts[0].gstreams

@@ -192,7 +192,8 @@ class Lanes:
         self.lanes = [trainer] + [NativeTrainer(trainer.kind, trainer.num_points, trainer.num_obj, trainer.device) for _ in range(self.n - 1)]
         for li, lane in enumerate(self.lanes):
             lane._salt = li * 1_000_003
-        self.streams = [torch.cuda.Stream(trainer.device) for _ in range(self.n)]
+        from .streams import concurrent_streams
+        self.streams = concurrent_streams(trainer.device, self.n)      # tested to run side by side (streams.py)
         self.pool = ThreadPoolExecutor(max_workers=self.n, thread_name_prefix="df-lane") if self.n > 1 else None
 
     def run(self, jobs):
