@@ -12,8 +12,9 @@ Different by design: the host only decodes the PNGs and finds the box; mask, ``c
 and the normalised crop of ALL requested frames of one crop size run as one HIP launch (``batch()``), and the tensors
 come back resident on the device (``.cuda()`` on them is a no-op).  The random pixel subset follows the key rule of
 include/dfusion.h; ``mask_to_bbox`` uses 8-connected components instead of OpenCV contours (same rectangles:
-findContours traces the outer border of exactly those components).  ``add_noise=True`` needs torchvision's
-ColorJitter (:82) and is refused.
+findContours traces the outer border of exactly those components).  ``add_noise=True`` (:114-115,159-160,178-180): colour
+jitter on the decoded frame (``augment.ColorJitter``, a restatement of the pinned torchvision's) and one random translation
+added to cloud and target.
 """
 from __future__ import annotations
 
@@ -26,6 +27,7 @@ from PIL import Image
 from scipy import ndimage
 
 from ...lib import preprocess as pp
+from .. import augment
 
 OBJLIST = [1, 2, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14, 15]
 IMG_H, IMG_W = 480, 640
@@ -84,13 +86,12 @@ def _load_yaml(path):
 
 class PoseDataset:
     def __init__(self, mode, num, add_noise, root, noise_trans, refine, device="cuda", seed=0):
-        if add_noise:
-            raise NotImplementedError("PoseDataset(add_noise=True) needs torchvision's ColorJitter; not available in this build")
         if mode not in ("train", "test", "eval"):
             raise ValueError(f"mode must be train / test / eval, got {mode!r}")
         self.objlist = list(OBJLIST)
         self.mode, self.num, self.root, self.refine = mode, int(num), root, refine
-        self.noise_trans = noise_trans
+        self.noise_trans, self.add_noise = noise_trans, bool(add_noise)
+        self.trancolor = augment.ColorJitter(0.2, 0.2, 0.2, 0.05)                  # :83
         self.device = torch.device(device)
         self.seed = int(seed)
         self.list_rgb, self.list_depth, self.list_label, self.list_obj, self.list_rank = [], [], [], [], []
@@ -135,7 +136,10 @@ class PoseDataset:
         return entries[0]
 
     def _host_frame(self, index):
-        rgb = np.asarray(Image.open(self.list_rgb[index]))[:, :, :3]
+        img = Image.open(self.list_rgb[index])
+        if self.add_noise:
+            img = self.trancolor(img)                         # :114-115
+        rgb = np.asarray(img)[:, :, :3]
         depth = np.asarray(Image.open(self.list_depth[index])).astype(np.uint16)
         label = np.asarray(Image.open(self.list_label[index]))
         obj, rank = self.list_obj[index], self.list_rank[index]
@@ -148,7 +152,7 @@ class PoseDataset:
             box = get_bbox(meta["obj_bb"])
         return np.ascontiguousarray(rgb), depth, np.ascontiguousarray(lab2d).astype(np.int32), box, obj, meta
 
-    def _targets(self, obj, meta):
+    def _targets(self, obj, meta, add_t=None):
         pts = self.pt[obj] / 1000.0
         n, keep_n = len(pts), self.num_pt_mesh_small
         keep = np.ones(n, dtype=bool)
@@ -156,6 +160,8 @@ class PoseDataset:
         model_points = pts[keep]                                           # (np.delete keeps the survivors in index order: so does this)
         target_r = np.resize(np.array(meta["cam_R_m2c"]), (3, 3))
         target = np.dot(model_points, target_r.T) + np.array(meta["cam_t_m2c"]) / 1000.0
+        if add_t is not None:
+            target = target + add_t                           # :178-179
         return torch.from_numpy(target.astype(np.float32)), torch.from_numpy(model_points.astype(np.float32))
 
     # -- device part: one launch per crop size -----------------------------------------------------------------
@@ -178,16 +184,18 @@ class PoseDataset:
                 prepared[k] = (cloud[j], choose[j], img[j]) if c else None
         out = []
         for k, h in enumerate(host):                     # index order: Python's global random stream is consumed like :129,167-170
-            for _ in range(3):
-                random.uniform(-self.noise_trans, self.noise_trans)        # add_t is drawn even when unused (:129)
+            add_t = np.array([random.uniform(-self.noise_trans, self.noise_trans) for _ in range(3)])      # drawn even when unused (:132)
             if prepared[k] is None:
                 cc = torch.LongTensor([0])
                 out.append((cc, cc, cc, cc, cc, cc))
                 continue
-            target, model_points = self._targets(h[4], h[5])
+            target, model_points = self._targets(h[4], h[5], add_t if self.add_noise else None)
             idx = torch.tensor([self.objlist.index(h[4])], dtype=torch.int64, device=dev)
             idx._host = [int(self.objlist.index(h[4]))]          # the trainer's losses branch on the index: spare it a device read-back
-            out.append(prepared[k] + (target.to(dev), model_points.to(dev), idx))
+            cloud, choose, img = prepared[k]
+            if self.add_noise:
+                cloud = cloud + torch.from_numpy(add_t.astype(np.float32)).to(dev)      # :159-160
+            out.append((cloud, choose, img, target.to(dev), model_points.to(dev), idx))
         return out
 
     def __getitem__(self, index):
@@ -201,15 +209,15 @@ class PoseDataset:
         rgb, depth, lab2d, box, obj, meta = self._host_frame(index)
         rmin, rmax, cmin, cmax = box
         count = int(np.count_nonzero((depth[rmin:rmax, cmin:cmax] != 0) & (lab2d[rmin:rmax, cmin:cmax] == 255)))
-        for _ in range(3):
-            random.uniform(-self.noise_trans, self.noise_trans)            # add_t is drawn even when unused (:129)
-        target, model_points = self._targets(obj, meta)
+        add_t = np.array([random.uniform(-self.noise_trans, self.noise_trans) for _ in range(3)])      # drawn even when unused (:132)
+        target, model_points = self._targets(obj, meta, add_t if self.add_noise else None)
         return (torch.from_numpy(np.array(rgb)), torch.from_numpy(depth.view(np.int16)), torch.from_numpy(lab2d),
-                torch.tensor([rmin, rmax, cmin, cmax, count, self.objlist.index(obj)], dtype=torch.int64), target, model_points)
+                torch.tensor([rmin, rmax, cmin, cmax, count, self.objlist.index(obj)], dtype=torch.int64), target, model_points,
+                torch.from_numpy((add_t if self.add_noise else np.zeros(3)).astype(np.float32)))
 
     def device_item(self, index, host):
         """Device half: uploads + one preparation launch on the current stream, no read-back.  Same 6-tuple as ``__getitem__``."""
-        rgb, depth, lab2d, info, target, model_points = host
+        rgb, depth, lab2d, info, target, model_points, add_t = host
         rmin, rmax, cmin, cmax, count, oi = (int(v) for v in info.tolist())
         if count == 0:
             cc = torch.LongTensor([0])
@@ -221,4 +229,6 @@ class PoseDataset:
                                                       self.num, cam=pp.LINEMOD_CAM)
         idx = torch.tensor([oi], dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
         idx._host = [oi]
+        if self.add_noise:
+            cloud = cloud + up(add_t)                         # :159-160 (the same translation went into the target)
         return (cloud[0], choose[0], img[0], up(target), up(model_points), idx)

@@ -16,6 +16,7 @@ BORDER_LIST = [-1, 40, 80, 120, 160, 200, 240, 280, 320, 360, 400, 440, 480, 520
 IMG_WIDTH, IMG_LENGTH = 480, 640            # eval_ycb.py:43-44 (rows, columns)
 YCB_CAM = dict(cx=312.9869, cy=241.3109, fx=1066.778, fy=1067.487, scale=10000.0)     # eval_ycb.py:37-41
 # datasets/linemod/dataset.py:73-76,152-157: back-projection in millimetres (cam_scale 1), finished cloud / 1000
+IMG_MEAN, IMG_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)      # the kernel's normalisation (applied to 0-255-scale pixels, eval_ycb.py:33)
 LINEMOD_CAM = dict(cx=325.26110, cy=242.04899, fx=572.41140, fy=573.57043, scale=1.0, cloud_div=1000.0)
 
 

@@ -172,3 +172,31 @@ def test_prefetch_threads_feed_the_native_trainer(tree):
     assert res["workers_8_frames_per_s"] > 0.4 * res["resident_frames_per_s"], res
     assert res["processes_8_frames_per_s"] > 2.0 * res["workers_0_frames_per_s"], res        # worker processes (0.89 of resident on 640 frames)
     assert res["processes_8_frames_per_s"] > 0.4 * res["resident_frames_per_s"], res
+
+
+def test_linemod_training_augmentation(tree):
+    """``add_noise=True`` (datasets/linemod/dataset.py:114-115,132,159-160,178-180): jittered colours, and ONE translation within
+    +-noise_trans added to the cloud and to the target; through ``__getitem__``, ``batch`` and the split fetch alike."""
+    _dev()
+    from densefusion_amd.datasets.linemod.dataset import PoseDataset
+    nt = 0.03
+    clean = PoseDataset("train", 500, False, tree, 0.0, False)
+    noisy = PoseDataset("train", 500, True, tree, nt, False)
+    for i in (0, 1, 14):
+        random.seed(300 + i)
+        a = clean[i]
+        random.seed(300 + i)
+        b = noisy[i]
+        shift = (b[0] - a[0]).cpu().numpy()
+        add_t = shift[0]
+        np.testing.assert_allclose(shift, np.broadcast_to(add_t, shift.shape), atol=1e-6)          # the same translation on every point
+        assert (np.abs(add_t) <= nt + 1e-6).all() and np.abs(add_t).max() > 0
+        assert torch.equal(a[1], b[1]) and a[2].shape == b[2].shape and not torch.equal(a[2], b[2])
+        meta = noisy._meta(noisy.list_obj[i], noisy.list_rank[i])
+        R, t = np.resize(np.array(meta["cam_R_m2c"]), (3, 3)), np.array(meta["cam_t_m2c"]) / 1000.0
+        want = b[4].cpu().numpy().astype(np.float64) @ R.T + t + add_t
+        np.testing.assert_allclose(b[3].cpu().numpy(), want, atol=2e-6)
+        random.seed(300 + i)
+        c = noisy.device_item(i, noisy.host_item(i))
+        for x, y in zip(b, c):
+            assert torch.equal(x.cpu(), y.cpu())

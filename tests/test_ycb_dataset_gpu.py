@@ -48,10 +48,32 @@ def make_tree(root, cfg, rng):
             Image.fromarray(label).save(f"{root}/{name}-label.png")
             scio.savemat(f"{root}/{name}-meta.mat", {"cls_indexes": np.array(present, dtype=np.uint8)[:, None], "poses": poses,
                                                      "factor_depth": np.array([[10000]], dtype=np.uint16)})
+    os.makedirs(f"{root}/data_syn")
+    syn = []
+    for fr in range(2):                                           # synthetic frames: RGBA renders on black, three objects each
+        name = f"data_syn/{fr:06d}"
+        syn.append(name)
+        label = np.zeros((480, 640), dtype=np.uint8)
+        present = [1, 2, 3]
+        for c in present:
+            h, w = int(rng.integers(150, 260)), int(rng.integers(200, 330))
+            r0, c0 = int(rng.integers(0, 480 - h)), int(rng.integers(0, 640 - w))
+            label[r0:r0 + h, c0:c0 + w][rng.random((h, w)) < 0.8] = c
+        rgba = rng.integers(0, 256, (480, 640, 4), dtype=np.uint8)
+        rgba[label == 0] = 0
+        rgba[..., 3] = np.where(label > 0, 255, 0)
+        depth = rng.integers(4000, 15000, (480, 640)).astype(np.uint16)
+        poses = np.stack([np.concatenate([synth.quat_to_rot(synth.random_unit_quaternion(rng)), rng.normal(size=(3, 1)) * 0.2 + [[0], [0], [1.0]]], axis=1)
+                          for _ in present], axis=2)
+        Image.fromarray(rgba).save(f"{root}/{name}-color.png")
+        Image.fromarray(depth).save(f"{root}/{name}-depth.png")
+        Image.fromarray(label).save(f"{root}/{name}-label.png")
+        scio.savemat(f"{root}/{name}-meta.mat", {"cls_indexes": np.array(present, dtype=np.uint8)[:, None], "poses": poses,
+                                                 "factor_depth": np.array([[10000]], dtype=np.uint16)})
     with open(f"{cfg}/test_data_list.txt", "w") as f:
         f.write("\n".join(names) + "\n")
     with open(f"{cfg}/train_data_list.txt", "w") as f:
-        f.write("\n".join(names[:2] + ["data_syn/000001"]) + "\n")
+        f.write("\n".join(names[:4] + syn) + "\n")
     return names
 
 
@@ -90,8 +112,54 @@ def test_ycb_dataset_matches_restatement(tmp_path, refine):
         assert torch.equal(got[2].cpu(), torch.from_numpy(img))
         np.testing.assert_array_equal(got[4].cpu().numpy(), model_points)
         np.testing.assert_allclose(got[3].cpu().numpy(), target, rtol=0, atol=1e-7)
-    tr = PoseDataset("train", N, False, root, 0.0, refine, dataset_config_dir=cfg)
-    with pytest.raises(NotImplementedError):
-        tr[2]                                                 # data_syn frame
-    with pytest.raises(NotImplementedError):
-        PoseDataset("train", N, True, root, 0.03, refine, dataset_config_dir=cfg)
+
+
+def test_ycb_training_augmentation(tmp_path):
+    """``add_noise=True`` and synthetic frames (datasets/ycb/dataset.py:117-136,149-167,196-221): one translation goes into cloud AND
+    target, occluders only ever remove mask pixels, a synthetic frame is pasted over a real background and gets pixel noise."""
+    from densefusion_amd.datasets.ycb.dataset import PoseDataset
+    rng = np.random.default_rng(4)
+    root, cfg = str(tmp_path / "YCB"), str(tmp_path / "cfg")
+    make_tree(root, cfg, rng)
+    N, nt = 1000, 0.03
+    clean = PoseDataset("train", N, False, root, 0.0, False, dataset_config_dir=cfg, seed=5)
+    noisy = PoseDataset("train", N, True, root, nt, False, dataset_config_dir=cfg, seed=5)
+    assert len(noisy) == 6 and len(noisy.syn) == 2 and len(noisy.real) == 4
+    occluded = 0
+    for i in range(4):                                            # real frames
+        np.random.seed(50 + i); random.seed(60 + i)
+        hc = clean.host_item(i)
+        np.random.seed(50 + i); random.seed(60 + i)
+        hn = noisy.host_item(i)
+        assert hn[0].shape == hc[0].shape == (480, 640, 3) and not torch.equal(hn[0], hc[0])         # jittered (and maybe occluded) colours
+        lab_c, lab_n = hc[2].numpy(), hn[2].numpy()
+        assert ((lab_n == lab_c) | (lab_n == 0)).all()                                                 # occluders only clear labels
+        occluded += int((lab_n != lab_c).any())
+        add_t = hn[4][5:8].numpy()
+        assert (np.abs(add_t) <= nt).all() and np.abs(add_t).max() > 0 and not hc[4][5:8].any()
+        # target = model_points R^T + t + add_t for the pose of the object that was drawn
+        meta = scio.loadmat(f"{root}/{noisy.list[i]}-meta.mat")
+        obj = meta["cls_indexes"].flatten().tolist()
+        pose = meta["poses"][:, :, obj.index(int(hn[3][4]))]
+        want = hn[6].numpy().astype(np.float64) @ pose[:, :3].T + pose[:, 3] + add_t
+        np.testing.assert_allclose(hn[5].numpy(), want, atol=1e-6)
+        item = noisy.device_item(i, hn)
+        base = noisy.device_item(i, hn[:4] + (torch.cat([hn[4][:5], torch.zeros(3, dtype=torch.float64)]),) + hn[5:])
+        np.testing.assert_allclose((item[0] - base[0]).cpu().numpy(), np.broadcast_to(add_t.astype(np.float32), (N, 3)), atol=1e-6)
+        assert torch.equal(item[1], base[1]) and torch.equal(item[2], base[2])
+    assert occluded >= 1
+    for i in (4, 5):                                              # synthetic frames, also without add_noise
+        for ds in (clean, noisy):
+            np.random.seed(70 + i); random.seed(80 + i)
+            h = ds.host_item(i)
+            assert int(h[3][5]) == 1
+            raw = np.array(Image.open(f"{root}/{ds.list[i]}-color.png"))[:, :, :3]
+            lab = np.array(Image.open(f"{root}/{ds.list[i]}-label.png"))
+            back = (lab == 0)
+            assert (h[0].numpy()[back] != raw[back]).any()                                           # a real frame shows through the background
+            a, b = ds.device_item(i, h), ds.device_item(i, h)
+            assert a[2].shape == b[2].shape and not torch.equal(a[2], b[2])                            # N(0, 7) pixel noise, drawn per fetch
+            assert float((a[2] - b[2]).std()) == pytest.approx(7.0 / 0.226 * 2 ** 0.5, rel=0.1)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    got = noisy[1]                                                # the plain __getitem__ goes the same way
+    assert len(got) == 6 and got[0].shape == (N, 3)

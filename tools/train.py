@@ -12,10 +12,11 @@ xGMI): every rank trains on its own shard of the frame list, gradients live in O
 (85.8 MB for PoseNet, 7.8 MB for the refiner) that is summed with ONE all-reduce per optimizer step; nothing
 else is communicated.  Launch: ``python -m torch.distributed.run --nproc-per-node N tools/train.py ...``.
 
-``--dataset synthetic`` trains on seeded synthetic frames (no dataset ships offline); ``ycb`` / ``linemod`` import
-``datasets.<name>.dataset.PoseDataset`` from the PYTHONPATH when it is there (the reference's loaders work unchanged: they
-return the 6-tuple cloud, choose, img, target, model_points, idx) and otherwise fall back to the built-in loaders
-(``densefusion_amd.datasets``), which prepare frames on the device but apply no augmentation.
+``--dataset synthetic`` trains on seeded synthetic frames (no dataset ships offline); ``ycb`` / ``linemod`` use the built-in
+loaders (``densefusion_amd.datasets``: the reference's constructor, file layout, 6-tuple and training augmentation -- colour jitter,
+occluders, synthetic frames over real backgrounds, pose-translation noise -- with the crop / sampling / back-projection on the
+device and the decode in worker processes); ``--reference_loaders`` imports ``datasets.<name>.dataset.PoseDataset`` from the
+PYTHONPATH instead (the reference's loaders work unchanged: they return the same 6-tuple).
 """
 from __future__ import annotations
 
@@ -75,6 +76,8 @@ def build_parser():
     ap.add_argument("--feed", type=str, default="processes", choices=["processes", "threads"],
                     help="processes: the disk datasets decode in --workers worker processes (the reference's DataLoader workers) and the "
                          "trainer's process only uploads; threads: --workers threads of the trainer's process do both (always for the synthetic set)")
+    ap.add_argument("--reference_loaders", action="store_true",
+                    help="import datasets.<name>.dataset.PoseDataset from the PYTHONPATH (the reference's loaders) instead of the built-in ones")
     ap.add_argument("--lanes", type=int, default=4,
                     help="PoseNet phase, native step: passes of one accumulation window run on this many concurrent lanes (own HIP stream, "
                          "host thread, workspace and gradient buffer each; gradients summed in lane order): bs = 1 passes fill a fraction "
@@ -119,20 +122,16 @@ def make_datasets(opt):
     if opt.dataset not in ("ycb", "linemod"):
         raise SystemExit("Unknown dataset")
     opt.num_objects, opt.num_points = (21, 1000) if opt.dataset == "ycb" else (13, 500)
-    try:        # the reference's loaders (with their augmentation: ColorJitter, occluders, noise) when they are on the PYTHONPATH
+    if opt.reference_loaders:        # the reference's own loaders from the PYTHONPATH (host-side preparation, its DataLoader semantics)
         PoseDataset = __import__("datasets.%s.dataset" % opt.dataset, fromlist=["PoseDataset"]).PoseDataset
         return (PoseDataset("train", opt.num_points, True, opt.dataset_root, opt.noise_trans, opt.refine_start),
                 PoseDataset("test", opt.num_points, False, opt.dataset_root, 0.0, opt.refine_start))
-    except ImportError:
-        logging.getLogger("train").warning("datasets.%s.dataset not importable: using the built-in loader WITHOUT augmentation "
-                                           "(no colour jitter / occluders / pose noise%s)", opt.dataset,
-                                           "; synthetic frames skipped" if opt.dataset == "ycb" else "")
+    # built-in loaders: the reference's constructor arguments (tools/train.py:57-66: augmentation on for the training set)
     if opt.dataset == "ycb":
         from densefusion_amd.datasets.ycb.dataset import PoseDataset
-        return (PoseDataset("train", opt.num_points, False, opt.dataset_root, 0.0, opt.refine_start, skip_synthetic=True),
-                PoseDataset("test", opt.num_points, False, opt.dataset_root, 0.0, opt.refine_start))
-    from densefusion_amd.datasets.linemod.dataset import PoseDataset
-    return (PoseDataset("train", opt.num_points, False, opt.dataset_root, 0.0, opt.refine_start),
+    else:
+        from densefusion_amd.datasets.linemod.dataset import PoseDataset
+    return (PoseDataset("train", opt.num_points, True, opt.dataset_root, opt.noise_trans, opt.refine_start),
             PoseDataset("test", opt.num_points, False, opt.dataset_root, 0.0, opt.refine_start))
 
 
