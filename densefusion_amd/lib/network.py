@@ -59,6 +59,7 @@ class _EngineModule(nn.Module):
         self._handle = None
         self._handle_dev = None
         self._uploaded = {}          # key -> (data_ptr, version)
+        self._plist = None
         self._ws = None
 
     # -- engine handle ---------------------------------------------------------------------------
@@ -75,7 +76,9 @@ class _EngineModule(nn.Module):
             self._uploaded = {}
         synced = False
         self._upload_keep = []       # converted temporaries of this batch of uploads: alive until the next forward has waited for the copies
-        for key, p in self.named_parameters():
+        if self._plist is None:      # (the module tree never changes: the walk is a quarter of a millisecond per call)
+            self._plist = list(self.named_parameters())
+        for key, p in self._plist:
             if p.device != device:
                 raise RuntimeError(f"parameter {key} is on {p.device}, input on {device}: call .cuda() first")
             tag = (p.data_ptr(), p._version)

@@ -71,8 +71,8 @@ def test_train_entry_point_shared_passes(tmp_path, monkeypatch, caplog):
 
 
 def test_train_on_fabricated_linemod_tree_with_builtin_loader(tmp_path, caplog):
-    """--dataset linemod without the reference's loader on the PYTHONPATH: the built-in loader (device-side preparation, no
-    augmentation) feeds the trainer; one epoch over a fabricated tree runs and reports a finite test distance."""
+    """--dataset linemod: the built-in loader (device-side preparation, the reference's training augmentation) feeds the
+    trainer; one epoch over a fabricated tree runs and reports a finite test distance."""
     import logging
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import train
@@ -151,3 +151,34 @@ def test_two_rank_resume_of_the_estimator_alone_keeps_the_refiners_in_sync(tmp_p
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
     assert out.returncode == 0, out.stdout[-3000:]
     assert "different weights" not in out.stdout and out.stdout.count("TEST FINISH") >= 1, out.stdout[-3000:]
+
+
+def test_refiner_phase_on_lanes_matches_one_lane(tmp_path):
+    """The refiner phase with the frames of a window on 3 lanes (own refiner step AND own copy of the frozen estimator per lane) trains
+    the same refiner as one lane: same data order, gradients summed in lane order (a different summation order: tolerance, not bits)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import train
+    from densefusion_amd import synth
+    train.SyntheticPoseDataset.CROPS = [(40, 40), (80, 40)]
+    os.makedirs(tmp_path / "ck", exist_ok=True)
+    torch.save({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.posenet_spec(3), 5).items()}, tmp_path / "ck" / "p.pth")
+    torch.save({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.refiner_spec(3), 6).items()}, tmp_path / "ck" / "r.pth")
+    got = {}
+    for lanes in (1, 3):
+        out = tmp_path / f"m{lanes}"
+        os.makedirs(out)
+        for f in ("p.pth", "r.pth"):
+            os.link(tmp_path / "ck" / f, out / f)
+        train.main(["--dataset", "synthetic", "--num_objects", "3", "--num_points", "64", "--synthetic_train_frames", "24", "--synthetic_test_frames", "2",
+                    "--batch_size", "12", "--nepoch", "2", "--resume_posenet", "p.pth", "--resume_refinenet", "r.pth", "--decay_margin", "1e9",
+                    "--refine_margin", "1e9", "--lanes", str(lanes), "--outf", str(out), "--log_dir", str(tmp_path / f"l{lanes}")])
+        ck = glob.glob(str(out / "pose_refine_model_1_*.pth"))
+        assert ck, os.listdir(out)
+        got[lanes] = torch.load(ck[0], map_location="cpu", weights_only=True)
+    moved = 0.0
+    start = torch.load(tmp_path / "ck" / "r.pth", weights_only=True)
+    for k in got[1]:
+        a, b = got[1][k].double(), got[3][k].double()
+        moved = max(moved, float((a - start[k].double()).abs().max()))
+        assert float((a - b).abs().max()) <= 2e-5 + 2e-3 * float((a - start[k].double()).abs().max()), k
+    assert moved > 1e-5                                                                      # it trained

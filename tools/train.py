@@ -131,6 +131,8 @@ def make_datasets(opt):
         from densefusion_amd.datasets.ycb.dataset import PoseDataset
     else:
         from densefusion_amd.datasets.linemod.dataset import PoseDataset
+    logging.getLogger("train").info("datasets.%s: the built-in loader (device-side preparation; training augmentation on, noise_trans %g)",
+                                    opt.dataset, opt.noise_trans)
     return (PoseDataset("train", opt.num_points, True, opt.dataset_root, opt.noise_trans, opt.refine_start),
             PoseDataset("test", opt.num_points, False, opt.dataset_root, 0.0, opt.refine_start))
 
@@ -202,6 +204,23 @@ def main(argv=None):
         from densefusion_amd.native_train import Lanes
         lanes = Lanes(native["posenet"], opt.lanes)
 
+    refine_lanes = []          # [Lanes] once the refiner phase has started
+
+    def start_refine_lanes():
+        """Refiner phase on lanes: every lane gets its own refiner step (workspace, gradient buffer) AND its own copy of the frozen
+        estimator (engine handle + workspace are per module), so the frames of a window run side by side like the PoseNet phase's."""
+        if not native or opt.lanes <= 1 or refine_lanes:
+            return
+        from densefusion_amd.native_train import Lanes
+        sync_module(estimator)
+        rl = Lanes(native["refiner"], opt.lanes)
+        rl.lanes[0].frozen_estimator = estimator
+        for lane in rl.lanes[1:]:
+            e = PoseNet(num_points=opt.num_points, num_obj=opt.num_objects)
+            e.load_state_dict(estimator.state_dict())
+            lane.frozen_estimator = e.to(dev).eval()
+        refine_lanes.append(rl)
+
     def optimizer_for(module):
         flat = native["posenet" if module is estimator else "refiner"] if native else train_utils.FlatParams(module)
         return flat, train_utils.FlatAdam(flat, lr=opt.lr)
@@ -213,6 +232,8 @@ def main(argv=None):
         return module
 
     flat, optimizer = optimizer_for(refiner if opt.refine_start else estimator)
+    if opt.refine_start:
+        start_refine_lanes()
     opt.sym_list = dataset.get_sym_list()
     opt.num_points_mesh = dataset.get_num_points_mesh()
     criterion = Loss(opt.num_points_mesh, opt.sym_list)
@@ -251,14 +272,14 @@ def main(argv=None):
         if not opt.refine_start:
             return (lane or native["posenet"]).step_posenet(img, points, choose, idx, target, model_points, sym, opt.w, dropout=True)["dis"]
         with torch.no_grad():                            # the frozen estimator of the refiner phase: the fused inference engine
-            pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx)
+            pred_r, pred_t, pred_c, emb = getattr(lane, "frozen_estimator", estimator)(img, points, choose, idx)
             new_points, new_target = [], []
             for b, f in enumerate(frames):
                 _, _, npt, ntg = criterion(pred_r[b:b + 1], pred_t[b:b + 1], pred_c[b:b + 1], f[3], f[4], f[5], f[0], opt.w, True)
                 new_points.append(npt); new_target.append(ntg)
             new_points, new_target = torch.cat(new_points), torch.cat(new_target)
         for _ in range(opt.iteration):
-            out = native["refiner"].step_refiner(new_points, emb, idx, new_target, model_points, sym)
+            out = (lane or native["refiner"]).step_refiner(new_points, emb, idx, new_target, model_points, sym)
             new_points, new_target = out["new_points"], out["new_target"]
         return out["dis"]
 
@@ -291,6 +312,16 @@ def main(argv=None):
         total.backward()
         return [float(d.detach()) for d in dists]
 
+    dis_host = [torch.zeros((), dtype=torch.float32).pin_memory() for _ in range(2)]
+    pending_log = []
+
+    def flush_log():
+        while pending_log:
+            ev, slot, ep, batch_no, count, bs = pending_log.pop(0)
+            ev.synchronize()
+            log.info("Train time %s Epoch %d Batch %d Frame %d Avg_dis:%f", time.strftime("%Hh %Mm %Ss", time.gmtime(time.time() - st_time)),
+                     ep, batch_no, count, float(slot) / bs)
+
     feeds = {}
 
     def feed(ds, order):
@@ -315,7 +346,7 @@ def main(argv=None):
         else:
             estimator.train()
         flat.zero_grad()
-        train_count, train_dis_avg = 0, 0.0
+        train_count = 0
         # this rank's shard of the epoch.  The permutation comes from a seed EVERY rank shares (seed + epoch), so the shards are
         # disjoint; all ranks take the same number of frames and therefore the same number of optimizer steps -- the gradient
         # all-reduce is a collective, a rank that ran one step fewer would leave the others waiting in it.  Lost-detection
@@ -343,8 +374,9 @@ def main(argv=None):
             for f in window:
                 by_size.setdefault(tuple(f[2].shape[-2:]), []).append(f)
             passes = [group[g0:g0 + max(1, opt.frames_per_pass)] for group in by_size.values() for g0 in range(0, len(group), max(1, opt.frames_per_pass))]
-            if lanes is not None and not opt.refine_start:
-                for d in lanes.run([(lambda lane, fs=fs: _run_pass_native(fs, lane)) for fs in passes]):
+            active = (refine_lanes[0] if refine_lanes else None) if opt.refine_start else lanes
+            if active is not None:
+                for d in active.run([(lambda lane, fs=fs: _run_pass_native(fs, lane)) for fs in passes]):
                     window_dis = window_dis + d.sum()
             else:
                 for fs in passes:
@@ -356,16 +388,20 @@ def main(argv=None):
             n = allreduce(flat)                                   # the one collective of the training path
             optimizer.step(grad_scale=1.0 / n)
             flat.zero_grad()
-            train_dis_avg = float(window_dis)             # the window's one read-back (the log line below needs the number)
+            # the window's one read-back (its log line needs the number) trails the launches by one window: an asynchronous copy into
+            # pinned memory now, waited for only after the NEXT window has been enqueued -- the device never idles on the host
+            slot = dis_host[(train_count // opt.batch_size) % 2]
+            slot.copy_(window_dis, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record()
             window_dis = torch.zeros((), device=dev)
-            log.info("Train time %s Epoch %d Batch %d Frame %d Avg_dis:%f", time.strftime("%Hh %Mm %Ss", time.gmtime(time.time() - st_time)),
-                     epoch, train_count // opt.batch_size, train_count, train_dis_avg / opt.batch_size)
-            train_dis_avg = 0.0
+            flush_log()
+            pending_log.append((ev, slot, epoch, train_count // opt.batch_size, train_count, opt.batch_size))
             if train_count // 1000 != prev // 1000 and rank == 0:
                 if opt.refine_start:
                     torch.save(sync_module(refiner).state_dict(), "{0}/pose_refine_model_current.pth".format(opt.outf))
                 else:
                     torch.save(sync_module(estimator).state_dict(), "{0}/pose_model_current.pth".format(opt.outf))
+        flush_log()
         log.info(">>>>>>>>----------epoch %d train finish---------<<<<<<<<", epoch)
 
         # per-epoch test pass (tools/train.py:181-209): the fused inference engine, no gradients
@@ -409,6 +445,7 @@ def main(argv=None):
             opt.refine_start = True
             opt.batch_size = max(1, int(opt.batch_size / opt.iteration))
             flat, optimizer = optimizer_for(refiner)
+            start_refine_lanes()
             if opt.dataset != "synthetic":
                 close_feeds()
                 dataset, test_dataset = make_datasets(opt)
