@@ -253,9 +253,10 @@ def main(argv=None):
         points, choose, img, target, model_points, idx = data
         if points.dim() == 1:                       # the LineMOD loader's "lost detection" sentinel: six LongTensor([0])
             return None
-        f = lambda t: t.to(dev)[None]                # add the bs = 1 axis the DataLoader of the reference adds
-        return (f(points), choose.to(dev).reshape(1, 1, -1), f(img), f(target), f(model_points),
-                train_utils.with_host_index(idx.to(dev).reshape(1, 1), getattr(idx, "_host", idx)))   # host copy kept: no read-back
+        on = lambda t: t if t.device == dev else t.to(dev)        # (the prefetcher hands over device tensors: no dispatch for a no-op)
+        f = lambda t: on(t)[None]                    # add the bs = 1 axis the DataLoader of the reference adds
+        return (f(points), on(choose).reshape(1, 1, -1), f(img), f(target), f(model_points),
+                train_utils.with_host_index(on(idx).reshape(1, 1), getattr(idx, "_host", idx)))   # host copy kept: no read-back
 
     def run_pass(frames):
         """Forward + loss + backward of `frames` (same crop size) in one pass; returns their distances (a device tensor [len(frames)]:
