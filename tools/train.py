@@ -408,7 +408,7 @@ def main(argv=None):
         # per-epoch test pass (tools/train.py:181-209): the fused inference engine, no gradients
         sync_module(refiner if opt.refine_start else estimator)
         estimator.eval(); refiner.eval()
-        test_dis, test_count = 0.0, 0
+        test_dis, test_count = torch.zeros((), dtype=torch.float64, device=dev), 0          # summed on the device: one read-back per test pass
         with torch.no_grad():
             for item in feed(test_dataset, range(rank, len(test_dataset), world)):
                 data = to_dev(item)
@@ -421,9 +421,9 @@ def main(argv=None):
                     for _ in range(opt.iteration):
                         pred_r, pred_t = refiner(new_points, emb, idx)
                         dis, new_points, new_target = criterion_refine(pred_r, pred_t, new_target, model_points, idx, new_points)
-                test_dis += float(dis)
+                test_dis = test_dis + dis.reshape(()).double()
                 test_count += 1
-        stats = torch.tensor([test_dis, float(test_count)], device=dev if opt.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+        stats = torch.tensor([float(test_dis), float(test_count)], device=dev if opt.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         if world > 1:
             dist.all_reduce(stats)
         test_dis = float(stats[0] / max(stats[1], 1.0))
