@@ -1342,7 +1342,7 @@ int launch_conv(const ConvParams &p, hipStream_t st, int *splitk_used) {
   int S = 1;
   if (v4 && p.splitk_ws && !p.colsum && p.zcount == 1 && loader != 0 && tiles < 256 && p.bias_group_ld == 0 && p.rows_per_group == 0) {
     const int nkt = (p.KH * p.KW * p.Cin) / 32;
-    S = (int)std::min<long>(8, (512 + tiles - 1) / tiles);
+    S = (int)std::min<long>(8, (1024 + tiles - 1) / tiles);          // one round of workgroups at 4 per CU (512: -1.2 % on the 8-frame training step)
     S = std::min(S, nkt / 4);
     while (S > 1 && (size_t)S * M * p.Cout * sizeof(float) > p.splitk_ws_bytes) --S;
     if ((long)S * M * p.Cout >= (1L << 31)) S = 1;
