@@ -1,5 +1,6 @@
 """Dev tool: frames/s of the native PoseNet training step with the reference's bs = 1 passes on 1 / 2 / 4 / 8 lanes (bench.py's
-training workload: 8 frames of 160x160 per optimizer step).  usage: lanes_sweep.py"""
+training workload: 8 frames of 160x160 per optimizer step).  usage: lanes_sweep.py [lane counts ...]   (default 1 2 4 8; the HIP
+runtime offers 4 hardware queues: more lanes than that share them)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -21,16 +22,7 @@ for n in [int(a) for a in sys.argv[1:]] or (1, 2, 4, 8):
     tr = NativeTrainer("posenet", N, K, dev)
     tr.load_state_dict(sd)
     opt = train_utils.FlatAdam(tr, lr=1e-4)
-    if os.environ.get("DF_SHIFT"):
-        _dummy = [torch.cuda.Stream(dev) for _ in range(int(os.environ["DF_SHIFT"]))]
-    if os.environ.get("DF_PREWARM"):
-        pre = [torch.cuda.Stream(dev) for _ in range(int(os.environ["DF_PREWARM"]))]
-        for st in pre:
-            with torch.cuda.stream(st):
-                torch.zeros(16, device=dev).add_(1)
-            st.synchronize()
     lanes = Lanes(tr, n)
-    print("streams", [hex(s.cuda_stream) for s in lanes.streams], flush=True)
 
     def window():
         jobs = [(lambda lane, i=i: lane.step_posenet(*[fr[k][i:i + 1] for k in ("img", "cloud", "choose", "obj", "target", "model_points")], sym[i:i + 1], 0.015,
