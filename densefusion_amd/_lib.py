@@ -49,7 +49,7 @@ SIGNATURES = {
     "df_loss_refine_backward": (_i, [_vp] * 5 + [_i, _f] + [_vp] * 3),
     "df_add_metric": (_i, [_vp] * 4 + [_i, _i, _vp, _vp]),
     "df_ycb_distances": (_i, [_vp] * 3 + [_i, _i, _vp, _vp, _vp]),
-    "df_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    "df_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "df_maxpool3s2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "df_maxpool2x2_idx": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "df_maxunpool2x2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),

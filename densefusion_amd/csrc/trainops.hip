@@ -16,7 +16,7 @@ inline int nblk(long n) { long b = (n + TB - 1) / TB; return (int)(b < 1 ? 1 : (
 
 // act: 1 = ReLU, 2 = PReLU (slope > 0 so sign(y) == sign(x)).  dx = dy * act'(x); PReLU also accumulates dslope.
 __global__ __launch_bounds__(TB) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, float *__restrict__ dx,
-                                                     long n, int act, const float *__restrict__ slope_p, float *__restrict__ dslope) {
+                                                     long n, int act, const float *__restrict__ slope_p, float *__restrict__ partials) {
   __shared__ float s_red[TB];
   const float slope = act == 2 ? slope_p[0] : 0.f;
   float ds = 0.f;
@@ -28,12 +28,21 @@ __global__ __launch_bounds__(TB) void act_bwd_kernel(const float *__restrict__ d
       if (act == 2) ds += g * (yy / slope);          // x = y / slope on the negative side
     }
   }
-  if (act == 2 && dslope) {
+  if (act == 2 && partials) {          // one partial per workgroup; act_bwd_finish_kernel adds them in index order (no float atomics)
     s_red[threadIdx.x] = ds;
     __syncthreads();
     for (int d = TB / 2; d >= 1; d >>= 1) { if (threadIdx.x < d) s_red[threadIdx.x] += s_red[threadIdx.x + d]; __syncthreads(); }
-    if (threadIdx.x == 0) atomicAdd(dslope, s_red[0]);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s_red[0];
   }
+}
+__global__ __launch_bounds__(TB) void act_bwd_finish_kernel(const float *__restrict__ partials, int nb, float *__restrict__ dslope) {
+  __shared__ float s_red[TB];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < nb; i += TB) a += partials[i];
+  s_red[threadIdx.x] = a;
+  __syncthreads();
+  for (int d = TB / 2; d >= 1; d >>= 1) { if (threadIdx.x < d) s_red[threadIdx.x] += s_red[threadIdx.x + d]; __syncthreads(); }
+  if (threadIdx.x == 0) dslope[0] += s_red[0];
 }
 
 // MaxPool2d(3, stride 2, pad 1) backward as a gather: every input pixel asks the <= 4 windows that cover it
@@ -141,25 +150,43 @@ __global__ __launch_bounds__(TB) void bilinear_fwd_kernel(const float *__restric
            wy1 * (wx0 * p[((long)y1 * W + x0) * C] + wx1 * p[((long)y1 * W + x1) * C]);
   }
 }
+// adjoint of the interpolation as a GATHER: every input element collects, in ascending (oy, ox) order, the output pixels whose two
+// source rows / columns include it (a conservative index range from the scale, each candidate re-tested with bil_src): fixed order,
+// no atomics -- the gradient is bit-reproducible
+__device__ __forceinline__ void bil_range(int i, int in_size, int out_size, int &lo, int &hi) {
+  const float inv = (float)out_size / (float)in_size;          // ~ output pixels per input pixel (either align mode, +-2 of slack below)
+  lo = (int)floorf(((float)i - 1.f) * inv) - 2;
+  hi = (int)ceilf(((float)i + 2.f) * inv) + 2;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > out_size - 1 ? out_size - 1 : hi;
+}
 __global__ __launch_bounds__(TB) void bilinear_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx, int B, int H, int W, int C,
                                                           int OH, int OW, int align) {
-  const long total = (long)B * OH * OW * C;
+  const long total = (long)B * H * W * C;
   GRID_STRIDE(i, total) {
     const int c = (int)(i % C);
     long r = i / C;
-    const int ox = (int)(r % OW); r /= OW;
-    const int oy = (int)(r % OH);
-    const int b = (int)(r / OH);
-    int y0, y1, x0, x1;
-    float wy0, wy1, wx0, wx1;
-    bil_src(oy, H, OH, align, y0, y1, wy0, wy1);
-    bil_src(ox, W, OW, align, x0, x1, wx0, wx1);
-    const float g = dy[i];
-    float *p = dx + (long)b * H * W * C + c;
-    atomicAdd(p + ((long)y0 * W + x0) * C, g * wy0 * wx0);
-    atomicAdd(p + ((long)y0 * W + x1) * C, g * wy0 * wx1);
-    atomicAdd(p + ((long)y1 * W + x0) * C, g * wy1 * wx0);
-    atomicAdd(p + ((long)y1 * W + x1) * C, g * wy1 * wx1);
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    int oy_lo, oy_hi, ox_lo, ox_hi;
+    bil_range(y, H, OH, oy_lo, oy_hi);
+    bil_range(x, W, OW, ox_lo, ox_hi);
+    const float *g = dy + (long)b * OH * OW * C + c;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float wy0, wy1;
+      bil_src(oy, H, OH, align, y0, y1, wy0, wy1);
+      const float wy = (y0 == y ? wy0 : 0.f) + (y1 == y ? wy1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1; float wx0, wx1;
+        bil_src(ox, W, OW, align, x0, x1, wx0, wx1);
+        const float wx = (x0 == x ? wx0 : 0.f) + (x1 == x ? wx1 : 0.f);
+        if (wx != 0.f) acc += g[((long)oy * OW + ox) * C] * wy * wx;
+      }
+    }
+    dx[i] = acc;
   }
 }
 
@@ -214,13 +241,30 @@ __global__ __launch_bounds__(TB) void gather_rows_kernel(const float *__restrict
     y[i] = x[j * C + (i - r * C)];
   }
 }
+// adjoint of the row gather without atomics: the FIRST source row that names a destination owns it and adds, in ascending source
+// order, every source row with the same index (wrap-padded `choose` repeats pixels) -- O(n) index reads per thread from an 8 KB
+// list, fixed order, bit-reproducible.  dx is zeroed by the caller.
 __global__ __launch_bounds__(TB) void scatter_add_rows_kernel(const float *__restrict__ dy, const int64_t *__restrict__ idx,
                                                               float *__restrict__ dx, long n, int C, long rows) {
   GRID_STRIDE(i, n * C) {
     const long r = i / C;
+    const int c = (int)(i - r * C);
     long j = idx[r];
     j = j < 0 ? 0 : (j >= rows ? rows - 1 : j);
-    atomicAdd(dx + j * C + (i - r * C), dy[i]);       // wrap-padded `choose` repeats pixels: contributions add up
+    bool owner = true;
+    for (long q = 0; q < r; ++q) {
+      long jq = idx[q];
+      jq = jq < 0 ? 0 : (jq >= rows ? rows - 1 : jq);
+      if (jq == j) { owner = false; break; }
+    }
+    if (!owner) continue;
+    float acc = dy[i];
+    for (long q = r + 1; q < n; ++q) {
+      long jq = idx[q];
+      jq = jq < 0 ? 0 : (jq >= rows ? rows - 1 : jq);
+      if (jq == j) acc += dy[q * C + c];
+    }
+    dx[j * C + c] = acc;
   }
 }
 
@@ -266,10 +310,16 @@ using namespace df;
 #define ST to_stream(stream)
 #define NN(p) if (!(p)) return set_error(DF_ERR_ARG, "%s: null pointer", __func__)
 
-extern "C" int df_act_bwd(const float *dy, const float *y, float *dx, int64_t n, int act, const float *slope, float *dslope, df_stream_t stream) {
+extern "C" int df_act_bwd(const float *dy, const float *y, float *dx, int64_t n, int act, const float *slope, float *dslope, float *partials,
+                          df_stream_t stream) {
   NN(dy); NN(y); NN(dx);
   if (act == 2 && !slope) return set_error(DF_ERR_ARG, "act_bwd: PReLU needs its slope");
-  if (n > 0) hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(n)), dim3(TB), 0, ST, dy, y, dx, (long)n, act, slope, dslope);
+  if (act == 2 && dslope && !partials) return set_error(DF_ERR_ARG, "act_bwd: the PReLU slope gradient needs DF_ACT_BWD_PARTIALS floats of scratch");
+  if (n > 0) {
+    const int nb = nblk(n);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(nb), dim3(TB), 0, ST, dy, y, dx, (long)n, act, slope, act == 2 && dslope ? partials : nullptr);
+    if (act == 2 && dslope) hipLaunchKernelGGL(act_bwd_finish_kernel, dim3(1), dim3(TB), 0, ST, partials, nb, dslope);
+  }
   return check_launch("act_bwd");
 }
 extern "C" int df_maxpool3s2_bwd(const float *x, const float *dy, float *dx, int B, int H, int W, int C, int OH, int OW, df_stream_t stream) {
@@ -287,10 +337,7 @@ extern "C" int df_bilinear(const float *in, float *out, int B, int H, int W, int
                            df_stream_t stream) {
   NN(in); NN(out);
   if (!backward) hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(nblk((long)B * OH * OW * C)), dim3(TB), 0, ST, in, out, B, H, W, C, OH, OW, align_corners);
-  else {
-    hipMemsetAsync(out, 0, (size_t)B * H * W * C * sizeof(float), ST);
-    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(nblk((long)B * OH * OW * C)), dim3(TB), 0, ST, in, out, B, H, W, C, OH, OW, align_corners);
-  }
+  else hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(nblk((long)B * H * W * C)), dim3(TB), 0, ST, in, out, B, H, W, C, OH, OW, align_corners);
   return check_launch("bilinear");
 }
 extern "C" int df_logsoftmax(const float *a, const float *y, float *out, int64_t rows, int C, int backward, df_stream_t stream) {

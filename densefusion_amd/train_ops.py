@@ -120,10 +120,12 @@ class ConvAct(torch.autograd.Function):
         with _lib.device_guard(x.device):
             if act:
                 g = torch.empty_like(dy)
+                partials = None
                 if has_slope:
                     dslope = torch.zeros(1, device=x.device)
+                    partials = torch.empty(16384, device=x.device)          # DF_ACT_BWD_PARTIALS: per-workgroup sums, added in order
                 _ck(L.df_act_bwd(dy.data_ptr(), y.data_ptr(), g.data_ptr(), dy.numel(), act, slope.data_ptr() if has_slope else None,
-                                 dslope.data_ptr() if has_slope else None, _st()), "act_bwd")
+                                 dslope.data_ptr() if has_slope else None, partials.data_ptr() if has_slope else None, _st()), "act_bwd")
             else:
                 g = dy
             d = _desc(x, w, None, stride, pad, dil)

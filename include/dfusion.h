@@ -153,8 +153,10 @@ int df_ycb_distances(const double *rt_est, const double *rt_gt, const double *pt
 
 /* Element-wise / resampling layers of the training graph (channels-last fp32), forward and backward; `backward != 0`
  * selects the adjoint (in = upstream gradient, out = input gradient).  See csrc/trainops.hip for the reference lines. */
+#define DF_ACT_BWD_PARTIALS 16384   /* floats of scratch the PReLU slope gradient needs (one partial per workgroup, added in order) */
 int df_act_bwd(const float *dy, const float *y, float *dx, int64_t n, int act /*1 ReLU, 2 PReLU*/, const float *slope,
-               float *dslope /* PReLU: += */, df_stream_t stream);
+               float *dslope /* PReLU: += */, float *partials /* PReLU with dslope: DF_ACT_BWD_PARTIALS floats; else may be NULL */,
+               df_stream_t stream);
 int df_maxpool3s2_fwd(const float *x, float *y, int B, int H, int W, int C, int OH, int OW, df_stream_t stream);
 /* MaxPool2d(2, 2, return_indices) / MaxUnpool2d(2, 2) of the SegNet encoder / decoder (vanilla_segmentation/segnet.py:78-116),
  * channels-last [B][H][W][C]; idx holds the winner's position 0..3 inside its 2x2 window (first maximum wins); unpool takes

@@ -248,3 +248,32 @@ def test_weight_gradients_are_bit_reproducible():
         (yr * torch.linspace(-1, 1, yr.numel(), device="cuda").view_as(yr)).sum().backward()
         # (db sums ~10^4 values of both signs in fp32 on both sides: cancellation leaves ~1e-4 of absolute noise)
         _close(got[0][0], wr.grad.cpu(), 2e-4, "dw"); _close(got[0][1], br.grad.cpu(), 1e-3, "db")
+
+
+def test_autograd_tape_step_is_bit_reproducible():
+    """The per-layer autograd-tape path (tools/train.py --autograd_tape) has no float atomics either: the bilinear adjoint and the
+    adjoint of the gather at wrap-padded `choose` are gathers in a fixed order, the PReLU slope gradient adds per-workgroup partials
+    in index order -- two identical steps give identical gradients, bit for bit, for EVERY parameter."""
+    from densefusion_amd.lib import train_graph
+    from densefusion_amd.lib.loss import Loss
+    from densefusion_amd.lib.network import PoseNet
+    K, N, H, W, M = 2, 64, 40, 80, 60
+    sd = synth.make_state_dict(synth.posenet_spec(K), 12)
+    o = synth.make_object(103, H, W, N, K, num_points_mesh=M)
+    few = np.sort(np.random.default_rng(1).choice(H * W, size=23, replace=False))
+    o["choose"] = np.resize(few, N).reshape(1, N).astype(np.int64)                  # wrap padding: repeated pixels
+    T = lambda k: torch.from_numpy(o[k])[None].cuda()
+    idx = torch.tensor([[1]]).cuda()
+    net = PoseNet(N, K)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.cuda().train()
+    crit = Loss(M, [1])
+    grads = []
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        r, t, c, _ = train_graph.posenet_forward(net, T("img"), T("cloud"), torch.from_numpy(o["choose"]).cuda(), idx, dropout=False)
+        crit(r, t, c, T("target"), T("model_points"), idx, T("cloud"), 0.015, False)[0].backward()
+        grads.append({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert len(grads[0]) >= 60
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
