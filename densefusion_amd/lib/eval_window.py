@@ -54,12 +54,17 @@ class WindowEstimator:
         slot = self.slots[self._n % len(self.slots)]
         self._n += 1
         main = slot["stream"]
-        self.copy_stream.wait_stream(torch.cuda.current_stream(self.dev))     # whatever filled the caller's buffers
-        with torch.cuda.stream(self.copy_stream):
+        # several windows in flight: the upload rides on the window's OWN stream (the other windows' compute overlaps it).  A separate
+        # copy stream would share one of the runtime's 4 hardware queues with some window's compute stream and every upload would
+        # queue behind that window (7 900 -> 8 300 poses/s through this class with 8 queues; with the default 4 this is the fix).
+        # One window at a time: a copy stream, so that the next upload overlaps this window's compute.
+        up = main if self.depth > 1 else self.copy_stream
+        up.wait_stream(torch.cuda.current_stream(self.dev))     # whatever filled the caller's buffers
+        with torch.cuda.stream(up):
             slot["rgb"][:F].copy_(rgb, non_blocking=True)
             slot["depth"][:F].copy_(depth.view(torch.int16) if depth.dtype != torch.int16 else depth, non_blocking=True)
             slot["label"][:F].copy_(label, non_blocking=True)
-            slot["ready"].record(self.copy_stream)
+            slot["ready"].record(up)
         main.wait_event(slot["ready"])
         n = len(detections)
         lost = np.zeros(n, dtype=bool)
