@@ -619,7 +619,7 @@ def main():
             self.pe = [PoseEstimator(est, ref) for _ in self.groups]          # one workspace per group (they may run concurrently)
             self.gstreams = None if (args.no_streams or len(self.groups) == 1) else [torch.cuda.Stream() for _ in self.groups]
             self.stream = inst_streams.pop() if inst_streams else torch.cuda.Stream()
-            self.graph = None
+            self.graph, self.pending = None, False
             run_step(self.pe, self.groups)                                     # eager pass: uploads weights, sizes the workspaces
             torch.cuda.synchronize()
             if not args.no_graph:
@@ -646,9 +646,12 @@ def main():
                     run_step(self.pe, self.groups, self.gstreams)
 
         def gather(self):      # results to every rank: the only communication of the inference path (a few KB per step)
-            torch.cuda.current_stream().wait_stream(self.stream)
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self.stream)
             mine = torch.cat([g["out"][1] for g in self.groups])
             dist.all_gather(gathered, mine if args.backend == "nccl" else mine.cpu())
+            self.stream.wait_stream(cur)          # the next step on this instance overwrites the outputs: after they were read
+            self.pending = False
 
     from densefusion_amd.streams import concurrent_streams
     # the steps in flight overlap only if their streams sit on different hardware queues: tested, not assumed (streams.py)
@@ -658,19 +661,30 @@ def main():
     graph, streams = insts[0].graph, insts[0].gstreams
 
     def timed_step(i):
+        # N > 1: a step's results are gathered when its instance comes round again (or by drain() at the end): by then the step has
+        # finished, so the wait the gather puts into the current stream -- which shares one of the runtime's 4 hardware queues with
+        # an instance's stream -- holds nothing up.  Every step is gathered exactly once, inside the timed region.
         inst = insts[i % len(insts)]
-        inst.launch()
-        if world > 1:
+        if world > 1 and inst.pending:
             inst.gather()
+        inst.launch()
+        inst.pending = world > 1
+
+    def drain():
+        for inst in insts:
+            if inst.pending:
+                inst.gather()
 
     for i in range(args.warmup):
         timed_step(i)
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         timed_step(i)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
