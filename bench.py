@@ -597,9 +597,12 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # DF_BENCH_FORCE_DIST=1 (test switch): run the N > 1 code path -- process group, per-step gather, barriers -- at world size 1
+    dist_on = world > 1 or bool(os.environ.get("DF_BENCH_FORCE_DIST"))
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":                  # "nccl" is RCCL on ROCm
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -609,7 +612,7 @@ def main():
     buckets = make_buckets(rank, world, args.per_bucket, device)
     poses_per_step = args.per_bucket * len(CROPS)
     gdev = device if args.backend == "nccl" else torch.device("cpu")
-    gathered = [torch.empty(poses_per_step, 7, dtype=torch.float64, device=gdev) for _ in range(world)] if world > 1 else None
+    gathered = [torch.empty(poses_per_step, 7, dtype=torch.float64, device=gdev) for _ in range(world)] if dist_on else None
 
     class Instance:
         """One step in flight: its own group workspaces, output buffers, stream and (captured) hipGraph; the inputs are shared."""
@@ -665,10 +668,10 @@ def main():
         # finished, so the wait the gather puts into the current stream -- which shares one of the runtime's 4 hardware queues with
         # an instance's stream -- holds nothing up.  Every step is gathered exactly once, inside the timed region.
         inst = insts[i % len(insts)]
-        if world > 1 and inst.pending:
+        if dist_on and inst.pending:
             inst.gather()
         inst.launch()
-        inst.pending = world > 1
+        inst.pending = dist_on
 
     def drain():
         for inst in insts:
@@ -678,7 +681,7 @@ def main():
     for i in range(args.warmup):
         timed_step(i)
     drain()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -686,10 +689,10 @@ def main():
         timed_step(i)
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], device=gdev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -743,7 +746,7 @@ def main():
             gpu_poses = bucket_poses(buckets, groups)
             out["cpu_baseline"], out["parity"] = cpu_baseline(buckets, gpu_poses)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

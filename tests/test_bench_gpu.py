@@ -64,3 +64,22 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=300)
     assert out.returncode != 0 and "WORLD_SIZE" in out.stderr and not out.stdout.strip()
+
+
+def test_bench_multi_rank_code_path_on_rccl_at_world_size_one():
+    """The N > 1 code path of bench.py -- process group on RCCL, the per-step all_gather of the poses next to four graph replays in
+    flight (gathered when an instance comes round again, drained at the end), barriers, the max-over-ranks all_reduce -- executed at
+    world size 1, the only RCCL world a one-GPU box offers (DF_BENCH_FORCE_DIST=1)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, DF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "9", "--warmup", "2", "--per-bucket", "4",
+                          "--no-knn", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["steps"] == 9 and d["value"] > 0
