@@ -283,3 +283,61 @@ def test_native_step_with_repeated_pixels_and_a_repeated_object():
         if "classifier" in key:
             continue
         _close(g, psd[key].grad, 3e-3, key)
+
+
+def test_native_steps_at_the_linemod_training_shape():
+    """LineMOD sizes (K = 13, N = 500 -- padded to 512 point rows inside the step --, M = 500, the symmetric 'eggbox' index 7): the
+    PoseNet step and the refiner step agree with the autograd-tape path at that shape too (the tape path is held to the oracle and
+    to the reference's backward)."""
+    from densefusion_amd import train_utils
+    from densefusion_amd.lib import train_graph
+    from densefusion_amd.lib.loss import Loss
+    from densefusion_amd.lib.loss_refiner import Loss_refine
+    from densefusion_amd.lib.network import PoseNet, PoseRefineNet
+    K, N, H, W, M = 13, 500, 120, 80, 500
+    sym_list = [7, 8]
+    sd = synth.make_state_dict(synth.posenet_spec(K), 31)
+    objs = [synth.make_object(305 + i, H, W, N, K, num_points_mesh=M) for i in range(2)]
+    objs[0]["obj"][0], objs[1]["obj"][0] = 7, 2
+    sym = [True, False]
+    f = _frames(objs)
+    net = PoseNet(N, K)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.to(DEV).train()
+    r, t, c, emb = train_graph.posenet_forward(net, f["img"], f["cloud"], f["choose"], f["obj"], dropout=False)
+    crit = Loss(M, sym_list)
+    total, new_pts, new_tgt = 0, [], []
+    for b in range(2):
+        ob = train_utils.with_host_index(f["obj"][b:b + 1], objs[b]["obj"])
+        loss, _, npt, ntg = crit(r[b:b + 1], t[b:b + 1], c[b:b + 1], f["target"][b:b + 1], f["model_points"][b:b + 1], ob, f["cloud"][b:b + 1], 0.015, False)
+        total = total + loss
+        new_pts.append(npt); new_tgt.append(ntg)
+    total.backward()
+    tr = _trainer("posenet", N, K, sd)
+    out = tr.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], sym, 0.015, dropout=False)
+    _close(out["loss"].sum(), total, 1e-4, "loss")
+    _close(out["new_points"], torch.cat(new_pts), 1e-4, "new_points")
+    got = tr.grad_dict()
+    for key, p in net.named_parameters():
+        if "classifier" not in key:
+            _close(got[key], p.grad, 2e-3, key)
+    # refiner step on the re-centred points (tools/train.py:156-159)
+    rsd = synth.make_state_dict(synth.refiner_spec(K), 32)
+    ref = PoseRefineNet(N, K)
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in rsd.items()})
+    ref.to(DEV).train()
+    pts, tgt, e = torch.cat(new_pts).detach(), torch.cat(new_tgt).detach(), emb.detach()
+    pr, pt = train_graph.refiner_forward(ref, pts, e, f["obj"])
+    crit_r = Loss_refine(M, sym_list)
+    total_r = 0
+    for b in range(2):
+        ob = train_utils.with_host_index(f["obj"][b:b + 1], objs[b]["obj"])
+        total_r = total_r + crit_r(pr[b:b + 1], pt[b:b + 1], tgt[b:b + 1], f["model_points"][b:b + 1], ob, pts[b:b + 1])[0]
+    total_r = total_r.reshape(())
+    total_r.backward()
+    rt = _trainer("refiner", N, K, rsd)
+    ro = rt.step_refiner(pts, e, f["obj"], tgt, f["model_points"], sym)
+    _close(ro["dis"].sum(), total_r, 1e-4, "dis")
+    rgot = rt.grad_dict()
+    for key, p in ref.named_parameters():
+        _close(rgot[key], p.grad, 2e-3, key)

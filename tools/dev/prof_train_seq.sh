@@ -5,7 +5,7 @@ set -eo pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export DF_TB_ONE_SIZE=1
 rm -rf gpurun_out/prof_seq
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_seq -- python3 tools/train_bench.py 8 1 > gpurun_out/prof_seq.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_seq -- python3 tools/train_bench.py ${P:-8} 1 > gpurun_out/prof_seq.log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/prof_seq/**/*kernel_trace.csv", recursive=True)[0]
