@@ -341,3 +341,32 @@ def test_native_steps_at_the_linemod_training_shape():
     rgot = rt.grad_dict()
     for key, p in ref.named_parameters():
         _close(rgot[key], p.grad, 2e-3, key)
+
+
+def test_refiner_step_at_the_ycb_refine_mesh_size():
+    """The refiner phase of YCB training samples 2600 model points (datasets/ycb/dataset.py:90-91,240-244): the symmetric branch is
+    then a 2600 x 2600 nearest-neighbour search per frame.  Native refiner step vs torch CPU autograd through the oracle, two frames
+    (one symmetric, one not)."""
+    K, N, M = 21, 1000, 2600
+    sd = synth.make_state_dict(synth.refiner_spec(K), 1013)
+    objs = [synth.make_object(403 + i, 80, 80, N, K, num_points_mesh=M) for i in range(2)]
+    objs[0]["obj"][0], objs[1]["obj"][0] = 19, 4
+    rng = np.random.default_rng(2)
+    emb = torch.from_numpy(rng.standard_normal((2, 32, N)).astype(np.float32))
+    psd = {k: torch.from_numpy(v).clone().requires_grad_() for k, v in sd.items()}
+    want, want_np, want_nt = 0, [], []
+    for b, o in enumerate(objs):
+        T = lambda k: torch.from_numpy(o[k])[None]
+        idx = torch.tensor([[int(o["obj"][0])]])
+        pr, pt = dfnet.refiner_forward(psd, T("cloud"), emb[b:b + 1], idx)
+        d, npt, ntg = loss_ref.loss_refine_calculation(pr, pt, T("target"), T("model_points"), idx, T("cloud"), M, [12, 15, 18, 19, 20])
+        want = want + d.reshape(())
+        want_np.append(npt); want_nt.append(ntg)
+    want.backward()
+    f = _frames(objs)
+    tr = _trainer("refiner", N, K, sd)
+    out = tr.step_refiner(f["cloud"], emb.to(DEV), f["obj"], f["target"], f["model_points"], [True, False])
+    _close(out["dis"].sum(), want, 1e-4, "dis")
+    _close(out["new_points"], torch.cat(want_np), 1e-4, "new_points"); _close(out["new_target"], torch.cat(want_nt), 1e-4, "new_target")
+    for key, g in tr.grad_dict().items():
+        _close(g, psd[key].grad, 2e-3, key)
