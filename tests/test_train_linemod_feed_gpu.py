@@ -29,3 +29,25 @@ def test_train_tool_on_a_linemod_tree(tmp_path, feed):
     log = r.stdout + r.stderr
     assert log.count("train finish") == 2, log[-3000:]                     # epochs 1 and 2
     assert any(f.startswith("pose_model_") for f in os.listdir(out / "models")), os.listdir(out / "models")
+
+
+def test_train_tool_on_a_ycb_tree_with_synthetic_frames(tmp_path):
+    """tools/train.py --dataset ycb on a fabricated YCB-Video tree: real and data_syn frames, the training augmentation (occluders,
+    backgrounds, jitter, noise) in worker processes, two epochs, a checkpoint."""
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_ycb_dataset_gpu import make_tree
+    root, cfg = str(tmp_path / "YCB"), str(tmp_path / "cfg")
+    make_tree(root, cfg, np.random.default_rng(9))
+    out = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "train.py"), "--dataset", "ycb", "--dataset_root", root, "--dataset_config_dir", cfg, "--nepoch", "3",
+           "--batch_size", "3", "--workers", "2", "--lanes", "2", "--outf", str(out / "models"), "--log_dir", str(out / "logs"), "--decay_margin", "0",
+           "--refine_margin", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    log = r.stdout + r.stderr
+    assert log.count("train finish") == 2 and "training augmentation on" in log, log[-3000:]
+    assert any(f.startswith("pose_model_") for f in os.listdir(out / "models")), os.listdir(out / "models")

@@ -67,6 +67,8 @@ def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dataset", type=str, default="synthetic", help="synthetic | ycb | linemod")
     ap.add_argument("--dataset_root", type=str, default="")
+    ap.add_argument("--dataset_config_dir", type=str, default="datasets/ycb/dataset_config",
+                    help="ycb: the directory of classes.txt / train_data_list.txt / test_data_list.txt (the reference keeps them in its tree)")
     ap.add_argument("--batch_size", type=int, default=8, help="frames accumulated per optimizer step and GPU")
     ap.add_argument("--frames_per_pass", type=int, default=1,
                     help="frames of equal crop size, out of one accumulation window, that share a forward/backward pass (1 = the "
@@ -133,8 +135,9 @@ def make_datasets(opt):
         from densefusion_amd.datasets.linemod.dataset import PoseDataset
     logging.getLogger("train").info("datasets.%s: the built-in loader (device-side preparation; training augmentation on, noise_trans %g)",
                                     opt.dataset, opt.noise_trans)
-    return (PoseDataset("train", opt.num_points, True, opt.dataset_root, opt.noise_trans, opt.refine_start),
-            PoseDataset("test", opt.num_points, False, opt.dataset_root, 0.0, opt.refine_start))
+    kw = dict(dataset_config_dir=opt.dataset_config_dir) if opt.dataset == "ycb" else {}
+    return (PoseDataset("train", opt.num_points, True, opt.dataset_root, opt.noise_trans, opt.refine_start, **kw),
+            PoseDataset("test", opt.num_points, False, opt.dataset_root, 0.0, opt.refine_start, **kw))
 
 
 def main(argv=None):
