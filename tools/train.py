@@ -102,8 +102,8 @@ def build_parser():
     ap.add_argument("--resume_posenet", type=str, default="")
     ap.add_argument("--resume_refinenet", type=str, default="")
     ap.add_argument("--start_epoch", type=int, default=1)
-    ap.add_argument("--outf", type=str, default="trained_models/synthetic")
-    ap.add_argument("--log_dir", type=str, default="experiments/logs/synthetic")
+    ap.add_argument("--outf", type=str, default="", help="default trained_models/<dataset> (tools/train.py:58-66 of the reference)")
+    ap.add_argument("--log_dir", type=str, default="", help="default experiments/logs/<dataset>")
     # synthetic-data knobs
     ap.add_argument("--num_objects", type=int, default=21)
     ap.add_argument("--num_points", type=int, default=1000)
@@ -158,6 +158,8 @@ def main(argv=None):
     np.random.seed(opt.seed + rank)
     logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format="%(message)s")
     log = logging.getLogger("train")
+    opt.outf = opt.outf or "trained_models/%s" % opt.dataset
+    opt.log_dir = opt.log_dir or "experiments/logs/%s" % opt.dataset
     os.makedirs(opt.outf, exist_ok=True)
     os.makedirs(opt.log_dir, exist_ok=True)
 
