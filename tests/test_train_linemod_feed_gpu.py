@@ -51,3 +51,6 @@ def test_train_tool_on_a_ycb_tree_with_synthetic_frames(tmp_path):
     log = r.stdout + r.stderr
     assert log.count("train finish") == 2 and "training augmentation on" in log, log[-3000:]
     assert any(f.startswith("pose_model_") for f in os.listdir(out / "models")), os.listdir(out / "models")
+    logs = sorted(os.listdir(out / "logs"))                                  # the reference's per-epoch log files (lib/utils.py)
+    assert logs == ["epoch_1_log.txt", "epoch_1_test_log.txt", "epoch_2_log.txt", "epoch_2_test_log.txt"], logs
+    assert "Avg_dis" in open(out / "logs" / "epoch_1_log.txt").read() and "TEST FINISH" in open(out / "logs" / "epoch_2_test_log.txt").read()

@@ -346,7 +346,22 @@ def main(argv=None):
     best_test = np.inf
     st_time = time.time()
     frames_seen = 0
+    def log_file(name):
+        """Per-epoch log files like the reference's setup_logger (lib/utils.py:3-17; tools/train.py:132,182): rank 0 only."""
+        if rank != 0:
+            return None
+        h = logging.FileHandler(os.path.join(opt.log_dir, name), mode="w")
+        h.setFormatter(logging.Formatter("%(asctime)s : %(message)s"))
+        log.addHandler(h)
+        return h
+
+    def close_log(h):
+        if h is not None:
+            log.removeHandler(h)
+            h.close()
+
     for epoch in range(opt.start_epoch, opt.nepoch):
+        fh = log_file("epoch_%d_log.txt" % epoch)
         if opt.refine_start:
             estimator.eval(); refiner.train()
         else:
@@ -409,6 +424,8 @@ def main(argv=None):
                     torch.save(sync_module(estimator).state_dict(), "{0}/pose_model_current.pth".format(opt.outf))
         flush_log()
         log.info(">>>>>>>>----------epoch %d train finish---------<<<<<<<<", epoch)
+        close_log(fh)
+        fh = log_file("epoch_%d_test_log.txt" % epoch)
 
         # per-epoch test pass (tools/train.py:181-209): the fused inference engine, no gradients
         sync_module(refiner if opt.refine_start else estimator)
@@ -433,6 +450,7 @@ def main(argv=None):
             dist.all_reduce(stats)
         test_dis = float(stats[0] / max(stats[1], 1.0))
         log.info("Test time %s Epoch %d TEST FINISH Avg dis: %f", time.strftime("%Hh %Mm %Ss", time.gmtime(time.time() - st_time)), epoch, test_dis)
+        close_log(fh)
         if test_dis <= best_test:
             best_test = test_dis
             if rank == 0:
