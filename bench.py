@@ -424,6 +424,27 @@ def bench_train(device):
         torch.cuda.synchronize()
         out["frames_per_s"][name] = round(reps * acc / (time.perf_counter() - t0), 1)
     out["lanes_1_per_pass"] = nstreams
+    # a window of frames of DIFFERENT crop sizes (what real data gives: no two frames can share a pass): bs = 1 passes on the lanes
+    mixed = []
+    for j in range(acc):
+        Hm, Wm = CROPS[j % len(CROPS)]
+        o = synth.make_object(700 + j, Hm, Wm, N, K, M)
+        o["obj"][0] = [12, 3, 15, 7][j % 4]
+        mixed.append(({k: torch.from_numpy(o[k])[None].to(device) for k in ("img", "cloud", "choose", "obj", "target", "model_points")},
+                      int(o["obj"][0]) in sym_list))
+
+    def mixed_window():
+        lanes.run([(lambda lane, f=f, sy=sy: lane.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], [sy], 0.015,
+                                                              dropout=True)) for f, sy in mixed])
+        train_utils.allreduce_gradients(tr); opt.step(grad_scale=1.0 / acc); tr.zero_grad()
+
+    mixed_window(); mixed_window()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        mixed_window()
+    torch.cuda.synchronize()
+    out["frames_per_s"]["1_per_pass_mixed_crop_sizes"] = round(4 * acc / (time.perf_counter() - t0), 1)
     lanes.close()
     del lanes
 
