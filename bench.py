@@ -50,17 +50,49 @@ def spawn_ranks(n, argv):
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
-    out, _ = procs[0].communicate()
+    # supervise every rank: rank 0's output is drained by a thread while all children are polled; the first rank that fails (or
+    # the overall deadline) ends the others -- a dead rank would otherwise leave the rest in a collective until the RCCL timeout
+    import threading
+    got = []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("DF_BENCH_DEADLINE_S", "1500"))
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0]} exited with status {rcs[bad[0]]}"
+        elif time.time() > deadline:
+            failed = "deadline exceeded"
+        if failed or all(rc is not None for rc in rcs):
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
     rcs = [p.wait() for p in procs]
+    reader.join(timeout=5)
+    out = got[0] if got else ""
+    if failed:
+        print(f"[bench] {failed}; rank exit codes {rcs}", file=sys.stderr)
+        for ln in (out or "").splitlines():
+            print(ln, file=sys.stderr)
+        first = next((rc for rc in rcs if rc), 1)
+        sys.exit(first if first > 0 else 1)
     line = None
     for ln in (out or "").splitlines():
         if ln.startswith("{"):
             line = ln
         else:
             print(ln, file=sys.stderr)
-    if any(rcs):
-        print(f"[bench] rank exit codes {rcs}", file=sys.stderr)
-        sys.exit(next(rc for rc in rcs if rc) if all(rc >= 0 for rc in rcs) else 1)
     if line is None or json.loads(line).get("n_gpus") != n:
         print(f"[bench] rank 0 did not report n_gpus == {n}: {line}", file=sys.stderr)
         sys.exit(1)
@@ -279,6 +311,12 @@ def bench_knn():
               "achieved_TFLOPs": round(9.0 * Bs * R * Qs / ms_s / 1e9, 2),
               "fp32_valu_frac": round(9.0 * Bs * R * Qs / ms_s / 1e9 / FP32_PEAK_TFLOPS, 4)}
     del refs, qrys
+    # the clock the device delivers under a vector-ALU load right after the stress launches (the peak the fractions are priced
+    # against assumes 2.4 GHz): box-to-box differences of the fraction show up here
+    mhz = ctypes.c_double()
+    _lib.check(_lib.lib().df_shader_clock_mhz(ctypes.byref(mhz), _lib.current_stream()), "shader_clock_mhz")
+    stress["shader_clock_mhz_under_valu_load"] = round(mhz.value, 1)
+    stress["fp32_valu_frac_at_delivered_clock"] = round(stress["fp32_valu_frac"] * 2400.0 / mhz.value, 4) if mhz.value > 0 else None
     return {"kernel": "knn1_dim3_sgpr_kernel (reference points through the scalar cache, 2 queries per lane)", "R": R, "Q": Q, "us_per_launch": round(us, 2), "stress_config5": stress,
             "algorithmic_bytes": byts, "achieved_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
             "algorithmic_flops": flops, "achieved_TFLOPs": round(tfl, 2), "fp32_valu_frac": round(tfl / FP32_PEAK_TFLOPS, 4),
@@ -507,6 +545,66 @@ def bench_train(device):
     return out
 
 
+def bench_config(K, N, crops, per_bucket, iters, device, wseed, cam=None, steps=6, inflight=2):
+    """poses/s of the whole path (PoseNet -> selection -> `iters` refine passes, df_estimate_poses_multi) on another BASELINE
+    configuration: `per_bucket` resident synthetic objects of every crop size in `crops` per step, the step captured as a hipGraph,
+    `inflight` instances alternating like the headline loop.  A side measurement: a few steps, never `value`."""
+    est, ref = PoseNet(N, K), PoseRefineNet(N, K)
+    est.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.posenet_spec(K), wseed).items()})
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.refiner_spec(K), wseed + 1000).items()})
+    est, ref = est.to(device).eval(), ref.to(device).eval()
+    imgs, cloud, choose, obj = [], [], [], []
+    for ci, (H, W) in enumerate(crops):
+        kw = {"cam": cam} if cam is not None else {}
+        objs = [synth.make_object(9000 + 100 * ci + i, H, W, N, K, **kw) for i in range(per_bucket)]
+        imgs.append(torch.from_numpy(np.stack([o["img"] for o in objs])).to(device))
+        cloud += [o["cloud"] for o in objs]; choose += [o["choose"] for o in objs]; obj += [o["obj"] for o in objs]
+    cloud, choose, obj = (torch.from_numpy(np.stack(a)).to(device) for a in (cloud, choose, obj))
+    n = per_bucket * len(crops)
+    insts = []
+    for _ in range(inflight):
+        pe = PoseEstimator(est, ref)
+        res = (torch.empty(n, 7, dtype=torch.float64, device=device), torch.empty(n, 7, dtype=torch.float64, device=device))
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            pe.estimate_multi(imgs, cloud, choose, obj, iters, out=res)
+            st.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+                pe.estimate_multi(imgs, cloud, choose, obj, iters, out=res)
+        insts.append((pe, res, st, g))
+    torch.cuda.synchronize()
+
+    def run(k):
+        for i in range(k):
+            _, _, st, g = insts[i % inflight]
+            with torch.cuda.stream(st):
+                g.replay()
+        torch.cuda.synchronize()
+
+    run(inflight)
+    t0 = time.perf_counter()
+    run(steps)
+    dt = time.perf_counter() - t0
+    finite = bool(torch.isfinite(insts[0][1][1]).all())
+    return {"poses_per_s": round(n * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "objects_per_step": n, "num_obj": K, "num_points": N,
+            "refine_iters": iters, "crops": [list(c) for c in crops], "steps": steps, "steps_in_flight": inflight, "hipgraph": True,
+            "poses_finite": finite}
+
+
+def bench_side_configs(device):
+    """The other BASELINE.json configurations as cheap side objects (the headline stays configs[2]'s shape at 2 iterations)."""
+    out = {}
+    out["linemod_cfg2"] = dict(bench_config(13, 500, [(80, 80), (120, 120), (120, 160), (160, 160)], 40, 2, device, WSEED + 7, cam=synth.LINEMOD_CAM),
+                               what="BASELINE configs[1]: LineMOD 13 objects, num_points=500, 2 refine iters, fp32, 4 crop sizes x 40 objects per step")
+    out["ycb_cfg3_iters4"] = dict(bench_config(K_OBJ, N_PTS, CROPS, 40, 4, device, WSEED),
+                                  what="BASELINE configs[2] as written: YCB 21 objects, num_points=1000, 4 refine iters, the headline's 7 crop sizes x 40 objects")
+    out["n2000_b64_forward"] = dict(bench_config(K_OBJ, 2000, [(240, 320)], 64, 2, device, WSEED + 3, steps=4),
+                                    what="BASELINE configs[4] shape through the forward path: num_points=2000, batch 64 objects of 240x320 per step, "
+                                         "2 refine iters (its KNN stress is knn.stress_config5)")
+    return out
+
+
 def host_threads():
     """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota (a GPU box
     exposes all host cores in os.cpu_count() but grants a 16-core share per GPU)."""
@@ -647,19 +745,16 @@ def main():
             run_step(self.pe, self.groups)                                     # eager pass: uploads weights, sizes the workspaces
             torch.cuda.synchronize()
             if not args.no_graph:
-                try:
-                    side = torch.cuda.Stream()
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        run_step(self.pe, self.groups, self.gstreams)
-                    torch.cuda.current_stream().wait_stream(side)
-                    self.graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime
-                        run_step(self.pe, self.groups, self.gstreams)
-                except Exception as e:                 # noqa: BLE001
-                    print(f"[bench] hipGraph capture failed ({e}); running eagerly", file=sys.stderr)
-                    self.graph = None
-                    torch.cuda.synchronize()
+                # a capture failure is FATAL: the headline is defined on the captured step (config.hipgraph); `--no-graph` is the
+                # only way to run it eagerly
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    run_step(self.pe, self.groups, self.gstreams)
+                torch.cuda.current_stream().wait_stream(side)
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime
+                    run_step(self.pe, self.groups, self.gstreams)
 
         def launch(self):
             """enqueue one step on this instance's stream (no host sync)"""
@@ -713,10 +808,27 @@ def main():
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
+    witness = None
     if dist_on:
+        my_dt = dt
         tmax = torch.tensor([dt], device=gdev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        # witness that the collective backend saw `world` DISTINCT devices: every rank contributes its device's UUID (16 bytes) and
+        # its own timed-region rate through one all_gather on the backend under test
+        props = torch.cuda.get_device_properties(device)
+        import hashlib
+        raw = hashlib.md5(f"{getattr(props, 'uuid', '')}|{getattr(props, 'pci_bus_id', '')}|{getattr(props, 'pci_device_id', '')}|"
+                          f"{getattr(props, 'pci_domain_id', '')}|{props.name}".encode()).digest()
+        mine = torch.tensor(list(raw[:16]) + [0.0], dtype=torch.float64, device=gdev)
+        mine[16] = poses_per_step * args.steps / my_dt
+        seen = [torch.empty(17, dtype=torch.float64, device=gdev) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        ids = {bytes(int(v) for v in t[:16].tolist()).hex() for t in seen}
+        rates = [float(t[16]) for t in seen]
+        witness = {"ranks_seen": len(seen), "distinct_devices": len(ids), "backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""),
+                   "per_rank_poses_per_s": {"min": round(min(rates), 1), "max": round(max(rates), 1)},
+                   "device_uuids": sorted(ids)}
 
     if rank == 0:
         total_poses = poses_per_step * world * args.steps
@@ -757,12 +869,15 @@ def main():
                            "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
                            "gemm_ms_per_step": round(ms / max(1, min(args.steps, 5)), 3)}
         assert out["n_gpus"] == args.gpus
+        if witness is not None:
+            out["collective_witness"] = witness
         if not args.no_knn and world == 1:          # the side measurements are single-GPU figures: not repeated per scaling point
             out["knn"] = bench_knn()
             out["knn"]["symmetric_loss_forward"] = bench_loss()
             out["latency_single_object"] = bench_latency(est, ref, device)
             out["entry_point"] = bench_entry_point(est, ref, device)
             out["train"] = bench_train(device)
+            out["configs"] = bench_side_configs(device)
         if world == 1 and not args.no_cpu_baseline:
             gpu_poses = bucket_poses(buckets, groups)
             out["cpu_baseline"], out["parity"] = cpu_baseline(buckets, gpu_poses)

@@ -29,6 +29,8 @@ SIGNATURES = {
     "df_version": (_i, []),
     "df_knn_device": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "df_knn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "knn_device": (None, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "df_shader_clock_mhz": (_i, [ctypes.POINTER(ctypes.c_double), _vp]),
     "df_posenet_create": (_vp, [_i, _i]),
     "df_refiner_create": (_vp, [_i, _i]),
     "df_net_destroy": (None, [_vp]),

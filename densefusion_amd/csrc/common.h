@@ -10,6 +10,8 @@
 
 namespace df {
 
+constexpr int DF_MAX_CROP = 3200;      // largest crop side the network entry points take (LDS tables of psp_prior_sum, layers.hip)
+
 int set_error(int code, const char *fmt, ...);   // records a thread-local message, returns code
 int check_launch(const char *what);              // hipGetLastError() -> DF_ERR_LAUNCH
 

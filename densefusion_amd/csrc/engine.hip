@@ -929,6 +929,9 @@ extern "C" int df_net_debug_tap_read(df_net *h, const char *name, float *dst, in
 static int posenet_args_ok(const Net *n, int B, int H, int W) {
   if (!n || n->kind != 0) return set_error(DF_ERR_ARG, "not a PoseNet handle");
   if (B <= 0 || H < 8 || W < 8) return set_error(DF_ERR_ARG, "posenet: need B >= 1 and H, W >= 8 (got %d, %d, %d)", B, H, W);
+  // psp_prior_sum keeps per-row / per-column interpolation tables of the 1/8-resolution map in LDS (12.8 KB + 64 (h + w) bytes <= 64 KB);
+  // the datasets' crops end at 480 x 640 (datasets/ycb/dataset.py:247-289)
+  if (H > DF_MAX_CROP || W > DF_MAX_CROP) return set_error(DF_ERR_ARG, "posenet: crops beyond %d pixels per side are not supported (got %d x %d)", DF_MAX_CROP, H, W);
   return DF_OK;
 }
 

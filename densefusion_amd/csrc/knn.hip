@@ -342,3 +342,15 @@ extern "C" int df_knn(const float *ref, const float *query, int64_t *idx, int ba
                       int query_nb, int k, df_stream_t stream) {
   return launch_knn(ref, query, idx, batch, dim, ref_nb, query_nb, k, df::to_stream(stream));
 }
+
+// Exact-signature drop-in for the reference's native entry point (lib/knn/src/knn_cuda_kernel.h:14-16, called at
+// lib/knn/src/knn_pytorch.c:35): same name, same argument list, void return.  `dist_dev` (the reference's ref_nb x query_nb
+// scratch, knn_pytorch.c:31) is IGNORED -- distances never leave registers here -- so a caller may pass NULL and skip the
+// allocation.  Errors cannot be returned through a void function: like the reference (whose wrapper polls cudaGetLastError,
+// knn_pytorch.c:41-45) the failure is left for the caller to find, here in df_last_error() / hipGetLastError().
+extern "C" void knn_device(float *ref_dev, int ref_width, float *query_dev, int query_width, int height, int k, float *dist_dev, long *ind_dev,
+                           df_stream_t stream) {
+  (void)dist_dev;
+  static_assert(sizeof(long) == sizeof(int64_t), "the reference's `long` indices are 64-bit on this ABI");
+  (void)launch_knn(ref_dev, query_dev, reinterpret_cast<int64_t *>(ind_dev), 1, height, ref_width, query_width, k, df::to_stream(stream));
+}

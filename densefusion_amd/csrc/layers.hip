@@ -620,7 +620,7 @@ void launch_psp_pool(const float *in, int in_ld, int in_coff, float *out, int B,
   hipLaunchKernelGGL(psp_pool_kernel, dim3(50 * ((B + 7) / 8) * 8), dim3(512), 0, st, in, in_ld, in_coff, out, B, H, W, C);
 }
 void launch_psp_prior_sum(const float *z, float *out, int B, int H, int W, int C, hipStream_t st) {
-  const size_t lds = ((size_t)50 * PP_CH + (size_t)16 * (H + W)) * sizeof(float);          // C % 64 == 0 (1024 here); H + W <= 1120
+  const size_t lds = ((size_t)50 * PP_CH + (size_t)16 * (H + W)) * sizeof(float);          // C % 64 == 0 (1024 here); 12.8 KB + 64 (H + W) bytes <= 64 KB: H + W <= 824 at 1/8 resolution, guaranteed by DF_MAX_CROP (posenet_args_ok)
   hipLaunchKernelGGL(psp_prior_sum_kernel, dim3(B * (C / PP_CH)), dim3(TPB), lds, st, z, out, B, H, W, C);
 }
 void launch_up3_patches(const float *x, const int64_t *choose, float *patch, int B, int h, int wd, int N, int Npad, hipStream_t st) {

@@ -1607,7 +1607,7 @@ extern "C" int df_posenet_train_step(df_trainer *h, const float *flat_param, flo
                                      float *loss_out, float *dis_out, float *new_points, float *new_target, float *out_r, float *out_t,
                                      float *out_c, float *emb, void *ws, size_t ws_bytes, df_stream_t stream) {
   if (!h || as_trainer(h)->kind != 0) return set_error(DF_ERR_ARG, "posenet_train_step: not a PoseNet trainer");
-  if (B <= 0 || H < 8 || W < 8 || M <= 0) return set_error(DF_ERR_ARG, "posenet_train_step: need B >= 1, H, W >= 8, M >= 1");
+  if (B <= 0 || H < 8 || W < 8 || M <= 0 || H > DF_MAX_CROP || W > DF_MAX_CROP) return set_error(DF_ERR_ARG, "posenet_train_step: need B >= 1, 8 <= H, W <= %d, M >= 1", DF_MAX_CROP);
   if (!flat_param || !flat_grad || !img || !cloud || !choose || !obj || !target || !model_points || !loss_out || !dis_out || !ws)
     return set_error(DF_ERR_ARG, "posenet_train_step: null pointer");
   Trainer &t = *as_trainer(h);

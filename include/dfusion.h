@@ -50,6 +50,16 @@ int df_knn_device(const float *ref_dev, int ref_nb, const float *query_dev, int 
 int df_knn(const float *ref, const float *query, int64_t *idx, int batch, int dim, int ref_nb, int query_nb,
            int k, df_stream_t stream);
 
+/* Exact-signature replacement of the reference's native symbol (lib/knn/src/knn_cuda_kernel.h:14-16): the call at
+ * lib/knn/src/knn_pytorch.c:35 binds to it unchanged.  `dist_dev` is ignored (may be NULL); `stream` is a hipStream_t;
+ * failures are reported through df_last_error() (the reference's wrapper polls the runtime's last error, knn_pytorch.c:41-45). */
+void knn_device(float *ref_dev, int ref_width, float *query_dev, int query_width, int height, int k, float *dist_dev,
+                long *ind_dev, df_stream_t stream);
+
+/* Measurement helper: the shader clock (MHz) the device delivers under a full-chip vector-ALU load right now (a ~1 ms spin kernel
+ * read against the constant 100 MHz counter).  Synchronises `stream`.  bench.py logs it next to the 1-NN roofline fractions. */
+int df_shader_clock_mhz(double *mhz_out, df_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Network handles (replace the nn.Module objects of lib/network.py; the Python classes of
  * densefusion_amd/lib/network.py own one handle each and keep the reference's state_dict keys)

@@ -18,13 +18,14 @@ def built_lib():
 def _declared():
     src = open(os.path.join(ROOT, "include", "dfusion.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(df_[a-z0-9_]+)\s*\(", src)))
+    # every df_* function plus `knn_device`, the reference's own native symbol (lib/knn/src/knn_cuda_kernel.h:14-16)
+    return sorted(set(re.findall(r"\b(df_[a-z0-9_]+|knn_device)\s*\(", src)))
 
 
 def test_header_symbols_exported(built_lib):
     L = ctypes.CDLL(built_lib)
     names = _declared()
-    assert "df_knn_device" in names and "df_knn" in names
+    assert "df_knn_device" in names and "df_knn" in names and "knn_device" in names
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/dfusion.h but not exported"
 

@@ -132,3 +132,28 @@ def test_knn1_random_sizes_bit_exact(knn_cls):
             qry[:, :, 0] = ref[:, :, 1]
         got = knn(torch.from_numpy(ref), torch.from_numpy(qry)).cpu().numpy()
         assert np.array_equal(got, knn_ref(ref, qry, 1)), (B, R, Q)
+
+
+def test_reference_symbol_knn_device_binds_with_the_references_argument_list():
+    """`extern "C" void knn_device(float*, int, float*, int, int, int, float*, long*, stream)` (lib/knn/src/knn_cuda_kernel.h:14-16) called
+    the way lib/knn/src/knn_pytorch.c:33-36 calls it: one call per batch entry, a distance scratch argument (ignored here: NULL)."""
+    import ctypes
+    from densefusion_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(21)
+    B, R, Q, k = 2, 500, 3001, 1
+    ref = (rng.random((B, 3, R), dtype=np.float32) - 0.5) * 0.2
+    qry = (rng.random((B, 3, Q), dtype=np.float32) - 0.5) * 0.25
+    r, q = torch.from_numpy(ref).cuda(), torch.from_numpy(qry).cuda()
+    idx = torch.zeros(B, k, Q, dtype=torch.int64, device="cuda")
+    for b in range(B):
+        L.knn_device(r[b].data_ptr(), R, q[b].data_ptr(), Q, 3, k, None, idx[b].data_ptr(), _lib.current_stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), knn_ref(ref, qry, 1))
+    # generic path (k = 2, dim = 5) through the same symbol
+    ref5 = rng.random((1, 5, 64), dtype=np.float32); qry5 = rng.random((1, 5, 200), dtype=np.float32)
+    r5, q5 = torch.from_numpy(ref5).cuda(), torch.from_numpy(qry5).cuda()
+    idx5 = torch.zeros(1, 2, 200, dtype=torch.int64, device="cuda")
+    L.knn_device(r5[0].data_ptr(), 64, q5[0].data_ptr(), 200, 5, 2, None, idx5[0].data_ptr(), _lib.current_stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(idx5.cpu().numpy(), knn_ref(ref5, qry5, 2))

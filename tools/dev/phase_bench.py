@@ -12,7 +12,7 @@ if __name__ == "__main__":
     for phase in ("posenet", "refiner"):
         with tempfile.TemporaryDirectory() as d:
             argv = ["--dataset", "synthetic", "--synthetic_train_frames", "256", "--synthetic_test_frames", "8", "--outf", d + "/m", "--log_dir", d + "/l",
-                    "--decay_margin", "0", "--refine_margin", "0"] + (["--refine_start"] if phase == "refiner" else []) + extra
+                    "--decay_margin", "0", "--refine_margin", "0", "--batch_size", "8"] + (["--refine_start"] if phase == "refiner" else []) + extra
             train_tool.main(argv + ["--nepoch", "2"])                                       # warm-up: library, workspaces, worker start
             t0 = time.perf_counter(); train_tool.main(argv + ["--nepoch", "2"]); t1 = time.perf_counter()     # 1 epoch (start_epoch = 1 .. nepoch - 1)
             train_tool.main(argv + ["--nepoch", "4"]); t2 = time.perf_counter()                                # 3 epochs

@@ -69,7 +69,7 @@ def build_parser():
     ap.add_argument("--dataset_root", type=str, default="")
     ap.add_argument("--dataset_config_dir", type=str, default="datasets/ycb/dataset_config",
                     help="ycb: the directory of classes.txt / train_data_list.txt / test_data_list.txt (the reference keeps them in its tree)")
-    ap.add_argument("--batch_size", type=int, default=8, help="frames accumulated per optimizer step and GPU")
+    ap.add_argument("--batch_size", type=int, default=32, help="frames accumulated per optimizer step and GPU (this fork's default, tools/train.py:34 of the reference; BASELINE configs[3] runs with --batch_size 8)")
     ap.add_argument("--frames_per_pass", type=int, default=1,
                     help="frames of equal crop size, out of one accumulation window, that share a forward/backward pass (1 = the "
                          "reference's bs = 1 passes; the gradients of a window are the same either way)")
@@ -87,13 +87,14 @@ def build_parser():
     ap.add_argument("--autograd_tape", action="store_true",
                     help="train through the per-layer autograd Functions of round 2 (lib/train_graph.py) instead of the native step "
                          "(csrc/train.hip: forward + loss + backward of a pass in one library call); same gradients, several times slower")
+    # optimisation defaults: THIS fork's (tools/train.py:34-42 of the reference), not upstream DenseFusion's
     ap.add_argument("--lr", type=float, default=0.0001)
-    ap.add_argument("--lr_rate", type=float, default=0.3)
+    ap.add_argument("--lr_rate", type=float, default=0.1)
     ap.add_argument("--w", type=float, default=0.015)
-    ap.add_argument("--w_rate", type=float, default=0.3)
-    ap.add_argument("--decay_margin", type=float, default=0.016)
-    ap.add_argument("--refine_margin", type=float, default=0.013)
-    ap.add_argument("--noise_trans", type=float, default=0.03)
+    ap.add_argument("--w_rate", type=float, default=0.1)
+    ap.add_argument("--decay_margin", type=float, default=0.03)
+    ap.add_argument("--refine_margin", type=float, default=0.02)
+    ap.add_argument("--noise_trans", type=float, default=0.005)
     ap.add_argument("--iteration", type=int, default=2)
     ap.add_argument("--nepoch", type=int, default=500)
     ap.add_argument("--repeat_epoch", type=int, default=0,
