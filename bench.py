@@ -482,9 +482,53 @@ def bench_train(device):
     for _ in range(4):
         mixed_window()
     torch.cuda.synchronize()
-    out["frames_per_s"]["1_per_pass_mixed_crop_sizes"] = round(4 * acc / (time.perf_counter() - t0), 1)
+    out["frames_per_s"]["1_per_pass_mixed_crop_sizes_on_lanes"] = round(4 * acc / (time.perf_counter() - t0), 1)
     lanes.close()
     del lanes
+
+    # the same mixed window as ONE multi-bucket pass (df_posenet_train_step_multi: what tools/train.py runs by default): bucketing and
+    # stacking of the window's frames included
+    mixed_frames = [dict(img=f["img"][0], cloud=f["cloud"][0], choose=f["choose"][0], obj=f["obj"][0], target=f["target"][0],
+                         model_points=f["model_points"][0], symmetric=sy) for f, sy in mixed]
+
+    def mixed_one_pass():
+        tr.step_posenet_window(mixed_frames, 0.015, dropout=True)
+        train_utils.allreduce_gradients(tr); opt.step(grad_scale=1.0 / acc); tr.zero_grad()
+
+    mixed_one_pass(); mixed_one_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(6):
+        mixed_one_pass()
+    torch.cuda.synchronize()
+    out["frames_per_s"]["1_per_pass_mixed_crop_sizes"] = round(6 * acc / (time.perf_counter() - t0), 1)
+    out["mixed_crop_sizes"] = [list(CROPS[j % len(CROPS)]) for j in range(acc)]
+
+    # roofline of the native step on EXECUTED FLOPs (df_trainer_profile: HIP events around every MFMA launch of the step on its stream;
+    # FLOPs = 2 M N K of the shapes really launched -- low-resolution up-convolutions, folded head layer 1, chosen-pixel up_3,
+    # F(4x4,3x3)-domain products -- not the reference graph's)
+    def profiled(fn, reps=3):
+        tr.profile(True)
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        prof = tr.profile_read()
+        tr.profile(False)
+        return {k: (ms / reps, fl / reps, n // reps) for k, (ms, fl, n) in prof.items()}
+
+    roof = {}
+    for name, fn, fps_key in (("8_per_pass", lambda: window(acc, False), "8_per_pass"), ("mixed_crop_sizes_one_pass", mixed_one_pass, "1_per_pass_mixed_crop_sizes")):
+        prof = profiled(fn)
+        ms_all = sum(v[0] for v in prof.values()); fl_all = sum(v[1] for v in prof.values())
+        wall_ms = acc / out["frames_per_s"][fps_key] * 1e3
+        roof[name] = {"kernel": "igemm_f32_v4 / v2 (forward, data gradient) + wgrad_f32_v2 (weight gradient), all MFMA launches of one optimizer window",
+                      "bound": "mfma", "unit": "TFLOP/s", "peak": FP32_PEAK_TFLOPS,
+                      "achieved": round(fl_all / ms_all / 1e9, 2), "frac": round(fl_all / ms_all / 1e9 / FP32_PEAK_TFLOPS, 4),
+                      "executed_gflop_per_window": round(fl_all / 1e9, 1), "mfma_ms_per_window": round(ms_all, 3), "wall_ms_per_window": round(wall_ms, 3),
+                      "whole_step_frac": round(fl_all / wall_ms / 1e9 / FP32_PEAK_TFLOPS, 4),
+                      "per_kind": {k: {"ms": round(ms, 3), "launches": n, "tflops": round(fl / ms / 1e9, 2) if ms > 0 else 0.0,
+                                       "frac": round(fl / ms / 1e9 / FP32_PEAK_TFLOPS, 4) if ms > 0 else 0.0} for k, (ms, fl, n) in prof.items()}}
+    out["roofline"] = roof
 
     # the autograd-tape path of round 2 on the same frames (comparison + per-kernel-kind rates)
     net = PoseNet(N, K)
@@ -539,9 +583,9 @@ def bench_train(device):
         wall_s = acc / out["frames_per_s"][f"{P}_per_pass"]
         fl = sum(v[1] for v in prof.values())
         whole[f"{P}_per_pass"] = {"conv_gflop_per_frame_reference_graph": round(fl / acc / 1e9, 1), "tflops_wall": round(fl / wall_s / 1e12, 2),
-                                  "frac_of_mfma_peak": round(fl / wall_s / 1e12 / FP32_PEAK_TFLOPS, 4)}
+                                  "reference_graph_flops_over_native_wall_frac": round(fl / wall_s / 1e12 / FP32_PEAK_TFLOPS, 4)}
     out["autograd_tape_conv_kernels"] = kinds
-    out["whole_step"] = whole
+    out["whole_step_reference_graph"] = whole
     return out
 
 

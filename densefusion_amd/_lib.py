@@ -80,6 +80,10 @@ SIGNATURES = {
     "df_trainer_unpack_param": (_i, [_vp, ctypes.c_char_p, _vp, _vp, _vp]),
     "df_posenet_train_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "df_posenet_train_step": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _f, _i, ctypes.c_uint] + [_vp] * 9 + [_sz, _vp]),
+    "df_posenet_train_multi_workspace_bytes": (_sz, [_vp, _i, _vp, _vp, _vp, _i]),
+    "df_posenet_train_step_multi": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp] + [_vp] * 5 + [_i, _vp, _f, _i, ctypes.c_uint] + [_vp] * 9 + [_sz, _vp]),
+    "df_trainer_profile": (_i, [_vp, _i]),
+    "df_trainer_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i)]),
     "df_refiner_train_workspace_bytes": (_sz, [_vp, _i, _i]),
     "df_refiner_train_step": (_i, [_vp, _vp, _vp, _i64, _i] + [_vp] * 5 + [_i, _vp] + [_vp] * 4 + [_sz, _vp]),
     "df_conv3x3_winograd_tile_scratch_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc), _i]),

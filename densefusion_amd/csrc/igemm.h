@@ -64,4 +64,15 @@ size_t wgrad_workspace_bytes(const ConvParams &p);
 // accumulate != 0: dw / db += this launch's gradient (accumulation over the frames of an optimizer step)
 int launch_wgrad(const ConvParams &p, float *dw, float *db, void *ws, size_t ws_bytes, hipStream_t st, int accumulate = 0);
 
+// The same gradient over SEVERAL crop-size buckets whose pixel rows are concatenated in p.in (input) and p.out (dY): bucket g =
+// B maps of H x W (outputs OH x OW) whose input / output pixel rows start at in_row0 / out_row0.  One contraction over the pixels of
+// all buckets (chunks of the pixel axis never straddle buckets), one fixed-order reduction: bit-reproducible.  p.B / H / W / OH / OW
+// are ignored; everything else (channels, strides, kernel geometry) comes from p.  Up to WGRAD_MAX_SEGS buckets per launch (more:
+// several launches, the later ones accumulating).
+constexpr int WGRAD_MAX_SEGS = 32;
+struct WgradSeg { int B, H, W, OH, OW; long in_row0, out_row0; };
+size_t wgrad_multi_workspace_bytes(const ConvParams &p, int nseg, const WgradSeg *segs);
+int launch_wgrad_multi(const ConvParams &p, int nseg, const WgradSeg *segs, float *dw, float *db, void *ws, size_t ws_bytes, hipStream_t st,
+                       int accumulate = 0);
+
 }  // namespace df

@@ -1037,26 +1037,44 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const ConvParams p, floa
 // the tile is 128 or 64 (Cout = 64 layers: up_2, up_3, layer1).  Every out-of-range element
 // (pixels beyond the chunk, padding taps, ragged Cout / K) is a bounds-checked buffer load that returns 0.
 // ------------------------------------------------------------------------------------------------
+// Several crop-size buckets in one launch (WgTab, by value): the pixel rows of the buckets are concatenated in p.in / p.out, bucket g is
+// tab.in_rows[g] input pixels from row tab.in_row0[g] and tab.M[g] output pixels from row tab.out_row0[g]; a workgroup's pixel chunk
+// (blockIdx.z) lies inside ONE bucket (chunks z0[g] .. z0[g + 1]), so the im2col decode uses that bucket's map size.
+struct WgTab {
+  int n;
+  int z0[WGRAD_MAX_SEGS + 1];
+  int H[WGRAD_MAX_SEGS], W[WGRAD_MAX_SEGS], OW[WGRAD_MAX_SEGS], ohw[WGRAD_MAX_SEGS], M[WGRAD_MAX_SEGS], in_rows[WGRAD_MAX_SEGS];
+  unsigned ohw_magic[WGRAD_MAX_SEGS], ow_magic[WGRAD_MAX_SEGS];
+  int ohw_sh[WGRAD_MAX_SEGS], ow_sh[WGRAD_MAX_SEGS];
+  long in_row0[WGRAD_MAX_SEGS], out_row0[WGRAD_MAX_SEGS];
+};
+
 template <int TN_>
-__global__ __launch_bounds__(256) void wgrad_f32_v2_kernel(const ConvParams p, float *__restrict__ part, int m_chunk) {
+__global__ __launch_bounds__(256) void wgrad_f32_v2_kernel(const ConvParams p, float *__restrict__ part, int m_chunk, const WgTab tab) {
   static_assert(TN_ == 64 || TN_ == 128, "n side of the tile");
   constexpr int TK_ = 128, RM = 32;
   constexpr int LDY = TN_ + 4, LDA = TK_ + 4;        // row strides: the second pixel of a step lands 4 banks further (2-way at worst)
-  constexpr int OPY = RM * LDY, OPA = RM * LDA;      // operand tiles (floats)
+  constexpr int OPY = RM * LDY;                      // the dY tile (floats); the A tile follows it
   constexpr int NI = TN_ / 64;                       // 32x32 accumulators per wave along n
   constexpr int VY = TN_ / 4, RPY = 256 / VY, PY = RM / RPY;      // dY loader: vectors per row, rows per pass, passes
   extern __shared__ __attribute__((aligned(16))) float smem[];      // [dY tile | A tile]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
-  const int M = p.B * p.OH * p.OW, K = p.KH * p.KW * p.Cin;
+  int sg = 0;
+  while (sg + 1 < tab.n && (int)blockIdx.z >= tab.z0[sg + 1]) ++sg;      // (workgroup-uniform: scalar loads of the table)
+  const int M = tab.M[sg], K = p.KH * p.KW * p.Cin;
+  const int sH = tab.H[sg], sW = tab.W[sg], sOW = tab.OW[sg];
+  const unsigned ohw_magic = tab.ohw_magic[sg], ow_magic = tab.ow_magic[sg];
+  const int ohw_sh = tab.ohw_sh[sg], ow_sh = tab.ow_sh[sg];
   const int tiles_k = (K + TK_ - 1) / TK_;
   const int n0 = (blockIdx.x / tiles_k) * TN_, k0 = (blockIdx.x % tiles_k) * TK_;
-  const int m_begin = blockIdx.z * m_chunk, m_end = min(M, m_begin + m_chunk);
+  const int m_begin = ((int)blockIdx.z - tab.z0[sg]) * m_chunk, m_end = min(M, m_begin + m_chunk);
   const int nt = (m_end - m_begin + RM - 1) / RM;
 
-  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, (unsigned)((size_t)p.B * p.H * p.W * p.in_ld * sizeof(float)), 0x00020000);
-  const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (unsigned)((size_t)M * p.out_ld * sizeof(float)), 0x00020000);
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in) + tab.in_row0[sg] * p.in_ld, 0,
+                                                      (unsigned)((size_t)tab.in_rows[sg] * p.in_ld * sizeof(float)), 0x00020000);
+  const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.out + tab.out_row0[sg] * p.out_ld, 0, (unsigned)((size_t)M * p.out_ld * sizeof(float)), 0x00020000);
 
   // loader of the A tile: this thread stages channel vector `vec` (4 floats) of the rows lrow + 8 i
   const int vec = tid & 31, lrow = tid >> 5;
@@ -1073,7 +1091,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_v2_kernel(const ConvParams p, f
   const int yvec = tid % VY, yrow = tid / VY;
   const int ncol = n0 + yvec * 4;
   const bool nok = ncol < p.Cout;
-  const int ohw = p.OH * p.OW;
+  const int ohw = tab.ohw[sg];
   u32x4 ry[PY], ra[4];
   auto issue_loads = [&](int t) {
 #pragma unroll
@@ -1086,11 +1104,11 @@ __global__ __launch_bounds__(256) void wgrad_f32_v2_kernel(const ConvParams p, f
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m_begin + t * RM + lrow + 8 * i;
-      const int b = fdiv(m, p.ohw_magic, p.ohw_sh, ohw), rem = m - b * ohw;
-      const int oy = fdiv(rem, p.ow_magic, p.ow_sh, p.OW), ox = rem - oy * p.OW;
+      const int b = fdiv(m, ohw_magic, ohw_sh, ohw), rem = m - b * ohw;
+      const int oy = fdiv(rem, ow_magic, ow_sh, sOW), ox = rem - oy * sOW;
       const int iy = oy * p.stride - p.pad + dyy, ix = ox * p.stride - p.pad + dxx;
-      const bool aok = m < m_end && kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      unsigned o = aok ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff + c) * 4u : 0xffffffffu;
+      const bool aok = m < m_end && kok && (unsigned)iy < (unsigned)sH && (unsigned)ix < (unsigned)sW;
+      unsigned o = aok ? (unsigned)(((b * sH + iy) * sW + ix) * p.in_ld + p.in_coff + c) * 4u : 0xffffffffu;
       asm("" : "+v"(o));
       ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, o, 0, 0);
     }
@@ -1393,50 +1411,77 @@ int launch_conv(const ConvParams &p, hipStream_t st, int *splitk_used) {
 namespace {
 struct WgradPlan { bool big; int tiles, split, chunk, nblk; size_t part_floats, bias_floats; };
 
-WgradPlan wgrad_plan(const ConvParams &p) {
+// `M`: pixels of the whole contraction; `chunks_of`: chunks a bucket of m pixels is cut into
+WgradPlan wgrad_plan(const ConvParams &p, int nseg, const WgradSeg *segs) {
   WgradPlan w{};
-  const int M = p.B * p.OH * p.OW, K = p.KH * p.KW * p.Cin;
+  long M = 0;
+  for (int g = 0; g < nseg; ++g) M += (long)segs[g].B * segs[g].OH * segs[g].OW;
+  const int K = p.KH * p.KW * p.Cin;
   w.big = p.Cout >= 64 && K >= 128;
   const int tn = w.big && p.Cout >= 128 ? 128 : 64, tk = w.big ? 128 : 64;
   w.tiles = ((p.Cout + tn - 1) / tn) * ((K + tk - 1) / tk);
   // split the pixel range so that one round of workgroups (4 per CU: 1024) is in flight, each with at least 256 pixels
-  int split = 1024 / w.tiles;
-  const int max_split = (M + 255) / 256;
+  long split = 1024 / w.tiles;
+  const long max_split = (M + 255) / 256;
   if (split > max_split) split = max_split;
   if (split > 256) split = 256;          // (the partial slices are re-read by the reduction)
   if (split < 1) split = 1;
-  w.chunk = ((M + split - 1) / split + 31) / 32 * 32;
-  w.split = (M + w.chunk - 1) / w.chunk;
-  w.nblk = (M + 127) / 128;
+  w.chunk = (int)(((M + split - 1) / split + 31) / 32 * 32);
+  w.split = 0;
+  for (int g = 0; g < nseg; ++g) w.split += (int)(((long)segs[g].B * segs[g].OH * segs[g].OW + w.chunk - 1) / w.chunk);
+  w.nblk = (int)((M + 127) / 128);
   w.part_floats = (size_t)w.split * p.Cout * K;       // (a single slice goes straight to dw unless the launch accumulates)
   w.bias_floats = (size_t)w.nblk * p.Cout;
   return w;
 }
+WgradSeg single_seg(const ConvParams &p) { return WgradSeg{p.B, p.H, p.W, p.OH, p.OW, 0, 0}; }
 }  // namespace
 
-size_t wgrad_workspace_bytes(const ConvParams &p) {
-  const WgradPlan w = wgrad_plan(p);
-  return (w.part_floats + w.bias_floats) * sizeof(float);
+size_t wgrad_multi_workspace_bytes(const ConvParams &p, int nseg, const WgradSeg *segs) {
+  size_t worst = 0;
+  for (int g0 = 0; g0 < nseg; g0 += WGRAD_MAX_SEGS) {
+    const WgradPlan w = wgrad_plan(p, std::min(WGRAD_MAX_SEGS, nseg - g0), segs + g0);
+    worst = std::max(worst, (w.part_floats + w.bias_floats) * sizeof(float));
+  }
+  return worst;
 }
 
-int launch_wgrad(const ConvParams &p0, float *dw, float *db, void *ws, size_t ws_bytes, hipStream_t st, int accumulate) {
-  ConvParams p = p0;
-  if (!p.in || !p.out || !dw) return set_error(DF_ERR_ARG, "wgrad: null pointer");
-  if (p.Cin % 4 || p.in_ld % 4 || p.in_coff % 4 || p.out_ld % 4 || p.out_coff % 4 || p.Cout % 4)
-    return set_error(DF_ERR_ARG, "wgrad: channel counts / strides / offsets must be multiples of 4");
-  if (p.up != 1 || p.zcount != 1) return set_error(DF_ERR_ARG, "wgrad: input dilation / grouped launches not supported");
-  const int M = p.B * p.OH * p.OW, K = p.KH * p.KW * p.Cin;
-  if (M <= 0) return DF_OK;
-  if ((size_t)p.B * p.H * p.W * p.in_ld * sizeof(float) >= (1ull << 32) || (size_t)M * p.out_ld * sizeof(float) >= (1ull << 32))
-    return set_error(DF_ERR_ARG, "wgrad: tensor too large (4 GB per operand)");
-  const WgradPlan w = wgrad_plan(p);
-  if (wgrad_workspace_bytes(p) > ws_bytes || (wgrad_workspace_bytes(p) && !ws)) return set_error(DF_ERR_WORKSPACE, "wgrad: workspace too small");
+size_t wgrad_workspace_bytes(const ConvParams &p) {
+  const WgradSeg sg = single_seg(p);
+  return wgrad_multi_workspace_bytes(p, 1, &sg);
+}
+
+static int launch_wgrad_segs(ConvParams p, int nseg, const WgradSeg *segs, float *dw, float *db, void *ws, size_t ws_bytes, hipStream_t st, int accumulate) {
+  const int K = p.KH * p.KW * p.Cin;
+  const WgradPlan w = wgrad_plan(p, nseg, segs);
+  const size_t need = (w.part_floats + w.bias_floats) * sizeof(float);
+  if (need > ws_bytes || (need && !ws)) return set_error(DF_ERR_WORKSPACE, "wgrad: workspace too small");
+  long M = 0, out_lo = segs[0].out_row0;
+  for (int g = 0; g < nseg; ++g) {
+    const WgradSeg &sg = segs[g];
+    if (sg.B <= 0 || sg.H <= 0 || sg.W <= 0 || sg.OH <= 0 || sg.OW <= 0) return set_error(DF_ERR_ARG, "wgrad: empty bucket");
+    if ((size_t)sg.B * sg.H * sg.W * p.in_ld * sizeof(float) >= (1ull << 32) || (size_t)sg.B * sg.OH * sg.OW * p.out_ld * sizeof(float) >= (1ull << 32))
+      return set_error(DF_ERR_ARG, "wgrad: tensor too large (4 GB per operand and bucket)");
+    if (sg.out_row0 != out_lo + M) return set_error(DF_ERR_ARG, "wgrad: the buckets' output rows must be contiguous and in order");
+    M += (long)sg.B * sg.OH * sg.OW;
+  }
+  if (M >= (1L << 31)) return set_error(DF_ERR_ARG, "wgrad: too many pixels");
   const bool reduce = w.split > 1 || accumulate;
   float *part = reduce ? static_cast<float *>(ws) : dw;
   float *bpart = static_cast<float *>(ws) + w.part_floats;
-  make_fdiv((long)p.OH * p.OW, p.ohw_magic, p.ohw_sh);
-  make_fdiv(p.OW, p.ow_magic, p.ow_sh);
   if (w.big) {
+    WgTab tab;
+    tab.n = nseg;
+    tab.z0[0] = 0;
+    for (int g = 0; g < nseg; ++g) {
+      const WgradSeg &sg = segs[g];
+      const long Mg = (long)sg.B * sg.OH * sg.OW;
+      tab.H[g] = sg.H; tab.W[g] = sg.W; tab.OW[g] = sg.OW; tab.ohw[g] = sg.OH * sg.OW; tab.M[g] = (int)Mg; tab.in_rows[g] = sg.B * sg.H * sg.W;
+      make_fdiv((long)sg.OH * sg.OW, tab.ohw_magic[g], tab.ohw_sh[g]);
+      make_fdiv(sg.OW, tab.ow_magic[g], tab.ow_sh[g]);
+      tab.in_row0[g] = sg.in_row0; tab.out_row0[g] = sg.out_row0;
+      tab.z0[g + 1] = tab.z0[g] + (int)((Mg + w.chunk - 1) / w.chunk);
+    }
     static bool attr_done[64] = {};
     int dev = 0;
     hipGetDevice(&dev);
@@ -1445,20 +1490,50 @@ int launch_wgrad(const ConvParams &p0, float *dw, float *db, void *ws, size_t ws
       hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_f32_v2_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
       attr_done[dev] = true;
     }
-    if (p.Cout >= 128) hipLaunchKernelGGL(wgrad_f32_v2_kernel<128>, dim3(w.tiles, 1, w.split), dim3(256), lds128, st, p, part, w.chunk);
-    else hipLaunchKernelGGL(wgrad_f32_v2_kernel<64>, dim3(w.tiles, 1, w.split), dim3(256), lds64, st, p, part, w.chunk);
+    if (p.Cout >= 128) hipLaunchKernelGGL(wgrad_f32_v2_kernel<128>, dim3(w.tiles, 1, w.split), dim3(256), lds128, st, p, part, w.chunk, tab);
+    else hipLaunchKernelGGL(wgrad_f32_v2_kernel<64>, dim3(w.tiles, 1, w.split), dim3(256), lds64, st, p, part, w.chunk, tab);
   } else {
-    hipLaunchKernelGGL(wgrad_f32_kernel, dim3(w.tiles, 1, w.split), dim3(256), 0, st, p, part, w.chunk);
+    // the small-shape kernel decodes one geometry: one launch per bucket into consecutive partial slices
+    int z = 0;
+    for (int g = 0; g < nseg; ++g) {
+      const WgradSeg &sg = segs[g];
+      ConvParams q = p;
+      q.B = sg.B; q.H = sg.H; q.W = sg.W; q.OH = sg.OH; q.OW = sg.OW;
+      q.in = p.in + sg.in_row0 * p.in_ld; q.out = p.out + sg.out_row0 * p.out_ld;
+      const int zc = (int)(((long)sg.B * sg.OH * sg.OW + w.chunk - 1) / w.chunk);
+      hipLaunchKernelGGL(wgrad_f32_kernel, dim3(w.tiles, 1, zc), dim3(256), 0, st, q, part + (size_t)z * p.Cout * K, w.chunk);
+      z += zc;
+    }
   }
   if (reduce) {
     const long n4 = (long)p.Cout * K / 4;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((n4 + 31) / 32, 8192)), dim3(256), 0, st, part, dw, n4, w.split, accumulate);
   }
-  if (db) {
-    hipLaunchKernelGGL(bias_grad_kernel, dim3((p.Cout + 63) / 64, w.nblk), dim3(256), 0, st, p.out, M, p.Cout, p.out_ld, p.out_coff, bpart, 128);
+  if (db) {     // dY's rows of all buckets are contiguous: one column sum over them
+    const float *dy = p.out + out_lo * p.out_ld;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((p.Cout + 63) / 64, w.nblk), dim3(256), 0, st, dy, (int)M, p.Cout, p.out_ld, p.out_coff, bpart, 128);
     hipLaunchKernelGGL(bias_reduce_kernel, dim3((p.Cout + 31) / 32), dim3(256), 0, st, bpart, db, p.Cout, w.nblk, accumulate);
   }
   return check_launch("wgrad");
+}
+
+int launch_wgrad_multi(const ConvParams &p, int nseg, const WgradSeg *segs, float *dw, float *db, void *ws, size_t ws_bytes, hipStream_t st, int accumulate) {
+  if (!p.in || !p.out || !dw || nseg <= 0 || !segs) return set_error(DF_ERR_ARG, "wgrad: null pointer");
+  if (p.Cin % 4 || p.in_ld % 4 || p.in_coff % 4 || p.out_ld % 4 || p.out_coff % 4 || p.Cout % 4)
+    return set_error(DF_ERR_ARG, "wgrad: channel counts / strides / offsets must be multiples of 4");
+  if (p.up != 1 || p.zcount != 1) return set_error(DF_ERR_ARG, "wgrad: input dilation / grouped launches not supported");
+  for (int g0 = 0; g0 < nseg; g0 += WGRAD_MAX_SEGS) {
+    const int rc = launch_wgrad_segs(p, std::min(WGRAD_MAX_SEGS, nseg - g0), segs + g0, dw, db, ws, ws_bytes, st, g0 ? 1 : accumulate);
+    if (rc != DF_OK) return rc;
+  }
+  return DF_OK;
+}
+
+int launch_wgrad(const ConvParams &p, float *dw, float *db, void *ws, size_t ws_bytes, hipStream_t st, int accumulate) {
+  if (!p.in || !p.out || !dw) return set_error(DF_ERR_ARG, "wgrad: null pointer");
+  if ((long)p.B * p.OH * p.OW <= 0) return DF_OK;
+  const WgradSeg sg = single_seg(p);
+  return launch_wgrad_multi(p, 1, &sg, dw, db, ws, ws_bytes, st, accumulate);
 }
 
 }  // namespace df

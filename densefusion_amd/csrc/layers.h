@@ -9,8 +9,9 @@ void launch_nchw3_to_nhwc4(const float *img, float *out, int B, int H, int W, hi
 // MaxPool2d(3, stride 2, pad 1) on NHWC (lib/extractors.py:84)
 void launch_maxpool3s2(const float *in, float *out, int B, int H, int W, int C, int OH, int OW, hipStream_t st);
 // AdaptiveAvgPool2d(s) for s in {1,2,3,6} (lib/pspnet.py:15-17); in = NHWC rows of width in_ld at channel
-// offset in_coff; out = 4 stage blocks of B*36 rows each ([4][B*36][C]; stage s fills its first B*s*s rows)
-void launch_psp_pool(const float *in, int in_ld, int in_coff, float *out, int B, int H, int W, int C, hipStream_t st);
+// offset in_coff; out = 4 stage blocks of B*36 rows each ([4][B*36][C]; stage s fills its first B*s*s rows).  Btot > 0: the stage blocks
+// hold Btot objects and this call fills objects b0 .. b0 + B (several crop-size buckets pooled into one set of stage blocks)
+void launch_psp_pool(const float *in, int in_ld, int in_coff, float *out, int B, int H, int W, int C, hipStream_t st, int Btot = 0, int b0 = 0);
 // sum over the 4 stages of F.upsample(size=(H,W), bilinear, align_corners=False) (lib/pspnet.py:22) of the
 // stage maps z ([4][B*36][C], already multiplied by the folded stage x bottleneck weights) -> out [B][H][W][C]
 void launch_psp_prior_sum(const float *z, float *out, int B, int H, int W, int C, hipStream_t st);

@@ -96,7 +96,7 @@ __device__ inline void psp_bin(int bin, int &s, int &local) {
 // once and the other three pyramid levels re-read it there (with the (bin, object) grid every XCD fetched every map: 3.6 TB/s of
 // reads for 0.13 of the algorithmic bandwidth).  Placement is for speed only: any placement gives the same sums.
 __global__ __launch_bounds__(512) void psp_pool_kernel(const float *__restrict__ in, int in_ld, int in_coff,
-                                                       float *__restrict__ out, int B, int H, int W, int C) {
+                                                       float *__restrict__ out, int B, int H, int W, int C, int Btot, int b0) {
   __shared__ f32x4 s_part[4][128];
   int s, local;
   const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512) void psp_pool_kernel(const float *__restrict__
   const int x0 = (j * W) / s, x1 = ((j + 1) * W + s - 1) / s;
   const float cnt = (float)((y1 - y0) * (x1 - x0));
   const int stage = s == 1 ? 0 : s == 2 ? 1 : s == 3 ? 2 : 3;
-  float *dst = out + ((size_t)stage * B * 36 + (size_t)b * s * s + local) * C;
+  float *dst = out + ((size_t)stage * Btot * 36 + (size_t)(b0 + b) * s * s + local) * C;      // stage blocks of Btot objects; this call fills objects b0 ..
   const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;         // 4 row-interleaved partial sums per channel vector
   for (int c0 = 0; c0 < C; c0 += 128 * 4) {
     const int c = c0 + tx * 4;
@@ -616,8 +616,8 @@ void launch_maxpool3s2(const float *in, float *out, int B, int H, int W, int C, 
   hipLaunchKernelGGL(maxpool3s2_kernel, dim3(blocks_for((long)B * OH * OW * (C / 4))), dim3(TPB), 0, st, in, out, B, H, W,
                      C / 4, OH, OW);
 }
-void launch_psp_pool(const float *in, int in_ld, int in_coff, float *out, int B, int H, int W, int C, hipStream_t st) {
-  hipLaunchKernelGGL(psp_pool_kernel, dim3(50 * ((B + 7) / 8) * 8), dim3(512), 0, st, in, in_ld, in_coff, out, B, H, W, C);
+void launch_psp_pool(const float *in, int in_ld, int in_coff, float *out, int B, int H, int W, int C, hipStream_t st, int Btot, int b0) {
+  hipLaunchKernelGGL(psp_pool_kernel, dim3(50 * ((B + 7) / 8) * 8), dim3(512), 0, st, in, in_ld, in_coff, out, B, H, W, C, Btot > 0 ? Btot : B, b0);
 }
 void launch_psp_prior_sum(const float *z, float *out, int B, int H, int W, int C, hipStream_t st) {
   const size_t lds = ((size_t)50 * PP_CH + (size_t)16 * (H + W)) * sizeof(float);          // C % 64 == 0 (1024 here); 12.8 KB + 64 (H + W) bytes <= 64 KB: H + W <= 824 at 1/8 resolution, guaranteed by DF_MAX_CROP (posenet_args_ok)

@@ -20,6 +20,7 @@
 #include <deque>
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -683,6 +684,12 @@ struct Trainer {
   size_t wino_floats = 0;
   FlipSeg *flip_tab = nullptr;     // device copy of `flips` for the one-launch flip
   long flip_total = 0;
+  // df_trainer_profile: HIP event pairs around every MFMA launch of a step, executed FLOPs per kind (0 fwd, 1 dgrad, 2 wgrad)
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;
+  size_t ev_used = 0;
+  std::vector<int> ev_kind;
+  std::vector<double> ev_flops;
 };
 
 size_t take(Trainer &t, const std::string &name, size_t floats) {
@@ -835,12 +842,32 @@ void build_refiner(Trainer &t) {
 // ------------------------------------------------------------------------------------------------
 struct View { float *d = nullptr; int ld = 0; };           // [rows][C] view: element (r, c) at d[r * ld + c] (d already offset to its channel)
 
+// One resolution level of a pass: the crop-size buckets' [B_i][H_i][W_i] blocks concatenated along the pixel-row axis (the inference
+// engine's scheme, engine.hip `Level`).  Launches whose arithmetic does not depend on the crop geometry (1x1 convolutions, the
+// Winograd-domain products, every weight gradient, the whole per-point part) cover the rows of all buckets at once; direct k x k
+// convolutions and the memory-bound glue run per bucket on row offsets into the same buffers.  Point rows are a single bucket.
+struct Lv {
+  std::vector<int> B, H, W;
+  std::vector<long> off;      // first pixel row of bucket i
+  std::vector<int> b0;        // first frame of bucket i
+  long rows = 0;
+  int frames = 0;
+  int nb() const { return (int)B.size(); }
+  void push(int b, int h, int w) {
+    B.push_back(b); H.push_back(h); W.push_back(w); off.push_back(rows); b0.push_back(frames);
+    rows += (long)b * h * w; frames += b;
+  }
+};
+
 struct Act {
   View v, g;                    // values; gradient (allocated / aliased during the backward pass)
-  int B = 1, H = 1, W = 1, C = 0;
+  const Lv *lv = nullptr;
+  int C = 0;
   bool gset = false;
-  long rows() const { return (long)B * H * W; }
+  long rows() const { return lv->rows; }
 };
+
+enum GemmKind { GK_FWD = 0, GK_DGRAD = 1, GK_WGRAD = 2 };
 
 struct Step {
   Trainer *t;
@@ -854,6 +881,7 @@ struct Step {
   float *splitk = nullptr;
   size_t splitk_bytes = 0;
   std::deque<Act> acts;
+  std::deque<Lv> lvs;
   std::vector<std::function<void()>> tape;
 
   void *bytes(size_t b) {
@@ -868,7 +896,8 @@ struct Step {
   }
   float *f(size_t n) { return static_cast<float *>(bytes(n * sizeof(float))); }
   bool live() const { return !dry && err == DF_OK; }
-  // DF_TRAIN_DEBUG=1: synchronise after every phase and name it on stderr (localises a faulting launch)
+#ifdef DF_DEV
+  // dev build, DF_TRAIN_DEBUG=1: synchronise after every phase and name it on stderr (localises a faulting launch)
   void dbg(const char *what, const std::string &extra = std::string()) {
     static const bool on = getenv("DF_TRAIN_DEBUG") != nullptr;
     if (!on || dry) return;
@@ -876,7 +905,34 @@ struct Step {
     fprintf(stderr, "[df-train] %s %s: %s\n", what, extra.c_str(), e == hipSuccess ? "ok" : hipGetErrorString(e));
     fflush(stderr);
   }
+#else
+  void dbg(const char *, const std::string & = std::string()) {}
+#endif
   void fail(int rc) { if (rc != DF_OK && err == DF_OK) err = rc; }
+  // every MFMA launch of the step goes through here: with df_trainer_profile on, HIP events on the launch stream bracket it and its
+  // EXECUTED FLOPs are tallied per kind (forward / data gradient / weight gradient)
+  void prof_begin() {
+    if (!t->profiling || !live()) return;
+    if (t->ev_used + 2 > t->ev.size()) {
+      const size_t old = t->ev.size();
+      t->ev.resize(old + 512);
+      for (size_t i = old; i < t->ev.size(); ++i) hipEventCreate(&t->ev[i]);
+    }
+    hipEventRecord(t->ev[t->ev_used], st);
+  }
+  void prof_end(int kind, double flops) {
+    if (!t->profiling || !live()) return;
+    hipEventRecord(t->ev[t->ev_used + 1], st);
+    t->ev_kind.push_back(kind);
+    t->ev_flops.push_back(flops);
+    t->ev_used += 2;
+  }
+  void gemm(int kind, const ConvParams &p) {
+    if (!live()) return;
+    prof_begin();
+    fail(launch_conv(p, st));
+    prof_end(kind, conv_flops(p));
+  }
   size_t slot(const std::string &name) {
     auto it = t->slot.find(name);
     if (it == t->slot.end()) {
@@ -888,14 +944,17 @@ struct Step {
   const float *p(const std::string &name, size_t extra = 0) { const size_t o = slot(name); return dry ? nullptr : P + o + extra; }
   float *gr(const std::string &name, size_t extra = 0) { const size_t o = slot(name); return dry ? nullptr : G + o + extra; }
   const float *pf(const std::string &name, size_t extra = 0) { const size_t o = slot(name); return dry ? nullptr : t->wflip + o + extra; }
-  Act *act(int B, int H, int W, int C, float *d = nullptr, int ld = 0) {
+  const Lv *level(const Lv &l) { lvs.push_back(l); return &lvs.back(); }
+  const Lv *flat_level(long rows) { Lv l; l.push((int)rows, 1, 1); return level(l); }
+  Act *act(const Lv *lv, int C, float *d = nullptr, int ld = 0) {
     acts.emplace_back();
     Act *a = &acts.back();
-    a->B = B; a->H = H; a->W = W; a->C = C;
-    a->v.d = d ? d : f((size_t)B * H * W * C);
+    a->lv = lv; a->C = C;
+    a->v.d = d ? d : f((size_t)lv->rows * C);
     a->v.ld = d ? ld : C;
     return a;
   }
+  Act *act(long rows, int C, float *d = nullptr, int ld = 0) { return act(flat_level(rows), C, d, ld); }
   // gradient storage of `a` for a producer that is about to write (returns true when it has to ACCUMULATE)
   bool grad_of(Act *a) {
     if (!a->g.d) { a->g.d = f((size_t)a->rows() * a->C); a->g.ld = a->C; }
@@ -905,11 +964,22 @@ struct Step {
   }
 };
 
-ConvParams base_params(const Act *x, int cin, const float *w, const float *bias, Act *y, int k, int stride, int pad, int dil, int act) {
+// a plain GEMM over all rows of x: every pixel / point row is one output row (1x1 convolution, stride 1)
+ConvParams flat_params(const Act *x, int cin, const float *w, const float *bias, Act *y, int act) {
   ConvParams p;
   p.in = x->v.d; p.wgt = w; p.bias = bias; p.out = y->v.d;
-  p.B = x->B; p.H = x->H; p.W = x->W; p.Cin = cin; p.in_ld = x->v.ld;
-  p.OH = y->H; p.OW = y->W; p.Cout = y->C; p.out_ld = y->v.ld;
+  p.B = (int)x->rows(); p.H = p.W = p.OH = p.OW = 1; p.Cin = cin; p.in_ld = x->v.ld;
+  p.Cout = y->C; p.out_ld = y->v.ld;
+  p.act = act;
+  return p;
+}
+// bucket i of a k x k convolution between two levels
+ConvParams bucket_params(const Act *x, int i, int cin, const float *w, const float *bias, Act *y, int k, int stride, int pad, int dil, int act) {
+  ConvParams p;
+  const Lv *li = x->lv, *lo = y->lv;
+  p.in = x->v.d + li->off[i] * x->v.ld; p.wgt = w; p.bias = bias; p.out = y->v.d + lo->off[i] * y->v.ld;
+  p.B = li->B[i]; p.H = li->H[i]; p.W = li->W[i]; p.Cin = cin; p.in_ld = x->v.ld;
+  p.OH = lo->H[i]; p.OW = lo->W[i]; p.Cout = y->C; p.out_ld = y->v.ld;
   p.KH = p.KW = k; p.stride = stride; p.pad = pad; p.dil = dil; p.act = act;
   return p;
 }
@@ -924,17 +994,28 @@ void launch_act_bwd(Step &s, Act *y, int act, const float *slope, float *dslope)
   if (act == 2) hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(TB), 0, s.st, part, (int)blocks, 1L, dslope, 1);
 }
 
-// weight / bias gradient of forward conv `f` with upstream gradient view gy, accumulated into dw / db
-void wgrad(Step &s, ConvParams f, View gy, float *dw, float *db) {
+// weight / bias gradient of a forward GEMM / convolution (`f`: channels, strides, kernel geometry; `segs`: the buckets) with upstream
+// gradient view gy, accumulated into dw / db: ONE contraction over the pixels of all buckets
+void wgrad(Step &s, ConvParams f, const std::vector<WgradSeg> &segs, View gy, float *dw, float *db) {
   f.out = gy.d; f.out_ld = gy.ld; f.out_coff = 0;
   f.bias = nullptr; f.res = nullptr; f.act = ACT_NONE; f.zcount = 1;
   f.rows_per_group = f.rows_valid = f.bias_group_ld = 0;
   const size_t mark = s.off;
-  const size_t need = wgrad_workspace_bytes(f);
+  const size_t need = wgrad_multi_workspace_bytes(f, (int)segs.size(), segs.data());
   void *ws = s.bytes(need);
-  if (s.live()) s.fail(launch_wgrad(f, dw, db, ws, need, s.st, 1));
+  if (s.live()) {
+    double M = 0;
+    for (const WgradSeg &g : segs) M += (double)g.B * g.OH * g.OW;
+    s.prof_begin();
+    s.fail(launch_wgrad_multi(f, (int)segs.size(), segs.data(), dw, db, ws, need, s.st, 1));
+    s.prof_end(GK_WGRAD, 2.0 * M * f.Cout * f.KH * f.KW * f.Cin);
+  }
   s.dbg("wgrad");
   s.off = mark;
+}
+// a launch that is one bucket by itself (plain GEMMs over rows; `f` carries B / H / W / OH / OW)
+void wgrad(Step &s, const ConvParams &f, View gy, float *dw, float *db) {
+  wgrad(s, f, std::vector<WgradSeg>{WgradSeg{f.B, f.H, f.W, f.OH, f.OW, 0, 0}}, gy, dw, db);
 }
 
 // data gradient of forward conv `f` (cached flipped weights): dx (+)= conv^T(gy)
@@ -949,7 +1030,7 @@ void dgrad(Step &s, const ConvParams &f, View gy, View dx, const float *wflip, b
     q.zcount = f.zcount; q.z_in_coff = f.z_out_coff; q.z_out_coff = f.z_in_coff; q.z_wgt = (long)f.Cin * f.Cout * f.KH * f.KW;
   }
   q.splitk_ws = s.splitk; q.splitk_ws_bytes = s.splitk_bytes;
-  if (s.live()) s.fail(launch_conv(q, s.st));
+  s.gemm(GK_DGRAD, q);
   s.dbg("dgrad");
 }
 
@@ -961,48 +1042,102 @@ struct ConvW {
   std::string slope;           // PReLU slope slot
 };
 
-// y = act(conv(x) + bias + res); registers its backward.  x_cin / x view: the first x_cin channels of x's view are consumed.
+View rows_view(View v, long row0) { return View{v.d + row0 * v.ld, v.ld}; }
+
+// y = act(conv(x) + bias + res); registers its backward.  The first `cin` channels of x's view are consumed.  A 1x1 stride-1
+// convolution is ONE GEMM over the rows of all buckets (forward, data and weight gradient); a k x k or strided one runs the direct
+// kernel per bucket -- or, for the stride-1 3x3 trunk layers whose map the engine's rule sends through F(4x4,3x3), one transform-domain
+// GEMM over the tiles of all such buckets, forward and data gradient alike -- and its weight gradient is one contraction over all
+// buckets' pixels (launch_wgrad_multi).
 Act *conv(Step &s, Act *x, int cin, const ConvW &cw, int cout, int k, int stride, int pad, int dil, int act, Act *res = nullptr, Act *into = nullptr,
           bool need_dx = true) {
-  Act *y = into ? into : s.act(x->B, conv_out(x->H, k, stride, pad, dil), conv_out(x->W, k, stride, pad, dil), cout);
-  ConvParams p = base_params(x, cin, s.p(cw.name, cw.woff), cw.bias.empty() ? nullptr : s.p(cw.bias, cw.boff), y, k, stride, pad, dil, act);
-  if (res) { p.res = res->v.d; p.res_ld = res->v.ld; }
-  if (act == ACT_PRELU) p.prelu = s.p(cw.slope);
-  p.splitk_ws = s.splitk; p.splitk_ws_bytes = s.splitk_bytes;
-  // stride-1 3x3 trunk convolutions whose map the engine's rule sends through F(4x4,3x3) take that route here too, forward and
-  // data gradient (the weight gradient stays in the spatial domain): DF_TRAIN_NO_WINOGRAD=1 keeps the direct kernel (A/B)
-  static const bool no_wino = getenv("DF_TRAIN_NO_WINOGRAD") != nullptr;
+  const Lv *li = x->lv;
+  const int nb = li->nb();
+  const bool flat = k == 1 && stride == 1 && pad == 0;
+  const Lv *lo = li;
+  if (!flat) {
+    Lv o;
+    for (int i = 0; i < nb; ++i) o.push(li->B[i], conv_out(li->H[i], k, stride, pad, dil), conv_out(li->W[i], k, stride, pad, dil));
+    lo = s.level(o);
+  }
+  Act *y = into ? into : s.act(lo, cout);
+  if (!flat && into) y->lv = lo;
+  const float *wp = s.p(cw.name, cw.woff), *bp = cw.bias.empty() ? nullptr : s.p(cw.bias, cw.boff);
+  const float *slope = act == ACT_PRELU ? s.p(cw.slope) : nullptr;
+  // the launches of the forward pass, kept for the backward closure
+  auto plan = std::make_shared<std::vector<ConvParams>>();
+  auto f4 = std::make_shared<std::vector<int>>();          // buckets on the F(4x4,3x3) route
   const auto wit = s.t->wino.find(cw.name);
-  const bool f4 = !no_wino && wit != s.t->wino.end() && k == 3 && stride == 1 && pad == dil && cw.bias.empty() && act != ACT_PRELU &&
-                  wino_route(x->H, x->W, dil, cin, cout) == 4;
-  auto wino_pass = [=](Step &s, View in, int ci, const float *U, View out, int co, const float *rs, int rs_ld, int a) {
-    const WinoGeom g = wino_geom(x->B, x->H, x->W, dil, 4);
+  const bool wino_ok = !flat && wit != s.t->wino.end() && k == 3 && stride == 1 && pad == dil && cw.bias.empty() && act != ACT_PRELU;
+  if (flat) {
+    ConvParams p = flat_params(x, cin, wp, bp, y, act);
+    if (res) { p.res = res->v.d; p.res_ld = res->v.ld; }
+    p.prelu = slope;
+    p.splitk_ws = s.splitk; p.splitk_ws_bytes = s.splitk_bytes;
+    plan->push_back(p);
+    s.gemm(GK_FWD, p);
+  } else {
+    for (int i = 0; i < nb; ++i) {
+      ConvParams p = bucket_params(x, i, cin, wp, bp, y, k, stride, pad, dil, act);
+      if (res) { p.res = res->v.d + lo->off[i] * res->v.ld; p.res_ld = res->v.ld; }
+      p.prelu = slope;
+      p.splitk_ws = s.splitk; p.splitk_ws_bytes = s.splitk_bytes;
+      plan->push_back(p);
+      if (wino_ok && wino_route(li->H[i], li->W[i], dil, cin, cout) == 4) f4->push_back(i);
+      else s.gemm(GK_FWD, p);
+    }
+  }
+  // transform-domain pass over the buckets of `f4` (stride 1: input and output levels have the same rows)
+  auto wino_pass = [=](Step &s, View in, int ci, const float *U, View out, int co, const float *rs, int rs_ld, int a, int kind) {
+    if (f4->empty()) return;
+    std::vector<int> tB, tH, tW;
+    std::vector<long> trow, t0;
+    long T = 0;
+    for (int i : *f4) {
+      tB.push_back(li->B[i]); tH.push_back(li->H[i]); tW.push_back(li->W[i]); trow.push_back(li->off[i]);
+      t0.push_back(T);
+      T += wino_geom(li->B[i], li->H[i], li->W[i], dil, 4).T;
+    }
     const size_t mark = s.off;
-    float *V = s.f((size_t)36 * g.T * ci), *M = s.f((size_t)36 * g.T * co);
+    float *V = s.f((size_t)36 * T * ci), *M = s.f((size_t)36 * T * co);
     if (s.live()) {
-      launch_wino_input(in.d, in.ld, 0, V, x->B, x->H, x->W, ci, dil, s.st, 0, 0, 4);
+      const int nw = (int)f4->size();
+      launch_wino4_input_multi(in.d, in.ld, V, nw, tB.data(), tH.data(), tW.data(), trow.data(), t0.data(), ci, dil, T, s.st);
       ConvParams q;
       q.in = V; q.wgt = U; q.out = M;
-      q.B = (int)g.T; q.Cin = ci; q.in_ld = ci; q.Cout = co; q.out_ld = co;
-      q.zcount = 36; q.z_in_coff = g.T * ci; q.z_wgt = (long)co * ci; q.z_out_coff = g.T * co;
-      s.fail(launch_conv(q, s.st));
-      launch_wino_output(M, out.d, out.ld, 0, nullptr, rs, rs_ld, 0, a, x->B, x->H, x->W, co, dil, s.st, 0, 0, 4);
+      q.B = (int)T; q.Cin = ci; q.in_ld = ci; q.Cout = co; q.out_ld = co;
+      q.zcount = 36; q.z_in_coff = T * ci; q.z_wgt = (long)co * ci; q.z_out_coff = T * co;
+      s.gemm(kind, q);
+      launch_wino4_output_multi(M, out.d, out.ld, rs, rs_ld, a, nw, tB.data(), tH.data(), tW.data(), trow.data(), t0.data(), co, dil, T, s.st);
     }
     s.off = mark;
   };
-  if (f4) wino_pass(s, x->v, cin, s.dry ? nullptr : s.t->wino_buf + wit->second.fwd, y->v, cout, res ? res->v.d : nullptr, res ? res->v.ld : 0, act);
-  else if (s.live()) s.fail(launch_conv(p, s.st));
+  wino_pass(s, x->v, cin, s.dry || !wino_ok ? nullptr : s.t->wino_buf + wit->second.fwd, y->v, cout, res ? res->v.d : nullptr, res ? res->v.ld : 0, act, GK_FWD);
   s.dbg("conv fwd", cw.name);
   Step *sp = &s;
   s.tape.push_back([=]() {
     Step &s = *sp;
     s.dbg("conv bwd begin", cw.name);
-    if (act != ACT_NONE) launch_act_bwd(s, y, act, act == ACT_PRELU ? s.p(cw.slope) : nullptr, act == ACT_PRELU ? s.gr(cw.slope) : nullptr);
-    wgrad(s, p, y->g, s.gr(cw.name, cw.woff), cw.bias.empty() ? nullptr : s.gr(cw.bias, cw.boff));
+    if (act != ACT_NONE) launch_act_bwd(s, y, act, slope, act == ACT_PRELU ? s.gr(cw.slope) : nullptr);
+    {   // weight gradient: one contraction over every bucket's pixels
+      std::vector<WgradSeg> segs;
+      if (flat) segs.push_back(WgradSeg{(int)x->rows(), 1, 1, 1, 1, 0, 0});
+      else for (int i = 0; i < nb; ++i) segs.push_back(WgradSeg{li->B[i], li->H[i], li->W[i], lo->H[i], lo->W[i], li->off[i], lo->off[i]});
+      ConvParams f = (*plan)[0];
+      f.in = x->v.d;
+      wgrad(s, f, segs, y->g, s.gr(cw.name, cw.woff), cw.bias.empty() ? nullptr : s.gr(cw.bias, cw.boff));
+    }
     if (need_dx) {
       const bool acc = s.grad_of(x);
-      if (f4) wino_pass(s, y->g, cout, s.dry ? nullptr : s.t->wino_buf + wit->second.bwd, x->g, cin, acc ? x->g.d : nullptr, x->g.ld, ACT_NONE);
-      else dgrad(s, p, y->g, x->g, s.pf(cw.name, cw.woff), acc);
+      if (flat) dgrad(s, (*plan)[0], y->g, x->g, s.pf(cw.name, cw.woff), acc);
+      else {
+        for (int i = 0; i < nb; ++i) {
+          bool on_f4 = false;
+          for (int j : *f4) on_f4 |= j == i;
+          if (!on_f4) dgrad(s, (*plan)[i], rows_view(y->g, lo->off[i]), rows_view(x->g, li->off[i]), s.pf(cw.name, cw.woff), acc);
+        }
+        wino_pass(s, y->g, cout, s.dry || !wino_ok ? nullptr : s.t->wino_buf + wit->second.bwd, x->g, cin, acc ? x->g.d : nullptr, x->g.ld, ACT_NONE, GK_DGRAD);
+      }
     }
     if (res) {
       if (!res->gset) { res->g = y->g; res->gset = true; }          // the residual's gradient IS this (masked) gradient: alias, no copy
@@ -1048,10 +1183,13 @@ int check_flips(Trainer &t, const float *P, long version, hipStream_t st) {
 // PoseNet step
 // ------------------------------------------------------------------------------------------------
 struct PoseNetIO {
-  int B, H, W, M;
-  const float *img, *cloud, *target, *model_points;
+  int nb;                        // crop-size buckets of the pass; frames are concatenated in bucket order everywhere below
+  const int *B, *H, *W;          // host [nb]
+  const float *const *img;       // host [nb]: device pointers [B_i][3][H_i][W_i]
+  int M;
+  const float *cloud, *target, *model_points;
   const int64_t *choose, *obj;
-  const int *symmetric;     // host [B]
+  const int *symmetric;     // host [sum B]
   float w;
   int dropout;
   unsigned seed;
@@ -1069,46 +1207,63 @@ Act *basic_block(Step &s, Act *x, int cin, const std::string &base, int planes, 
 // Dropout2d (lib/pspnet.py:46,52): one keep / drop decision per (frame, channel); out of place -- the PReLU gradient upstream needs
 // the un-scaled activation
 Act *dropout2d(Step &s, Act *a, float p, unsigned seed) {
-  float *scale = s.f((size_t)a->B * a->C);
-  Act *o = s.act(a->B, a->H, a->W, a->C);
+  const Lv *lv = a->lv;
+  float *scale = s.f((size_t)lv->frames * a->C);
+  Act *o = s.act(lv, a->C);
   if (s.live()) {
-    s.fail(df_dropout2d_mask(scale, (int64_t)a->B * a->C, seed, p, s.st));
-    s.fail(df_channel_scale(a->v.d, scale, o->v.d, a->B, (int64_t)a->H * a->W, a->C, s.st));
+    s.fail(df_dropout2d_mask(scale, (int64_t)lv->frames * a->C, seed, p, s.st));
+    for (int i = 0; i < lv->nb(); ++i)
+      s.fail(df_channel_scale(a->v.d + lv->off[i] * a->v.ld, scale + (size_t)lv->b0[i] * a->C, o->v.d + lv->off[i] * o->v.ld, lv->B[i],
+                              (int64_t)lv->H[i] * lv->W[i], a->C, s.st));
   }
   Step *sp = &s;
   s.tape.push_back([=]() {
     Step &s = *sp;
     s.grad_of(a);
-    if (s.live()) s.fail(df_channel_scale(o->g.d, scale, a->g.d, a->B, (int64_t)a->H * a->W, a->C, s.st));
+    if (s.live())
+      for (int i = 0; i < lv->nb(); ++i)
+        s.fail(df_channel_scale(o->g.d + lv->off[i] * o->g.ld, scale + (size_t)lv->b0[i] * a->C, a->g.d + lv->off[i] * a->g.ld, lv->B[i],
+                                (int64_t)lv->H[i] * lv->W[i], a->C, s.st));
   });
   return o;
 }
 
-// PSPUpsample through the low-resolution per-tap products (layers.hip upconv_gather): x [B][h][w][Cin] -> [B][2h][2w][Cout]
+// PSPUpsample through the low-resolution per-tap products (layers.hip upconv_gather): x [B][h][w][Cin] -> [B][2h][2w][Cout] per bucket;
+// the product, its weight and data gradients, the activation / bias adjoints are single launches over the rows of all buckets
 Act *upconv(Step &s, Act *x, const std::string &base, int cin, int cout) {
-  const int B = x->B, h = x->H, w = x->W;
-  Act *y = s.act(B, h, w, 9 * cout);
+  const Lv *li = x->lv;
+  const int nb = li->nb();
+  Act *y = s.act(li, 9 * cout);
   const ConvW cw{base + "conv.1.weight"};
-  ConvParams p = base_params(x, cin, s.p(cw.name), nullptr, y, 1, 1, 0, 1, ACT_NONE);
+  ConvParams p = flat_params(x, cin, s.p(cw.name), nullptr, y, ACT_NONE);
   p.splitk_ws = s.splitk; p.splitk_ws_bytes = s.splitk_bytes;
-  if (s.live()) s.fail(launch_conv(p, s.st));
-  Act *o = s.act(B, 2 * h, 2 * w, cout);
-  if (s.live()) s.fail(launch_upconv_gather(y->v.d, s.p(base + "conv.1.bias"), s.p(base + "conv.2.weight"), o->v.d, B, h, w, cout, s.st));
+  s.gemm(GK_FWD, p);
+  Lv up;
+  for (int i = 0; i < nb; ++i) up.push(li->B[i], 2 * li->H[i], 2 * li->W[i]);
+  const Lv *lo = s.level(up);
+  Act *o = s.act(lo, cout);
+  if (s.live())
+    for (int i = 0; i < nb; ++i)
+      s.fail(launch_upconv_gather(y->v.d + li->off[i] * 9 * cout, s.p(base + "conv.1.bias"), s.p(base + "conv.2.weight"), o->v.d + lo->off[i] * cout, li->B[i],
+                                  li->H[i], li->W[i], cout, s.st));
   Step *sp = &s;
   s.tape.push_back([=]() {
     Step &s = *sp;
     launch_act_bwd(s, o, ACT_PRELU, s.p(base + "conv.2.weight"), s.gr(base + "conv.2.weight"));
     {   // bias gradient: column sums of the pre-activation gradient over all pixels
       const long rows = o->rows();
-      const int nb = (int)((rows + 255) / 256);
-      float *part = s.f((size_t)nb * cout);
+      const int nbk = (int)((rows + 255) / 256);
+      float *part = s.f((size_t)nbk * cout);
       if (s.live()) {
-        hipLaunchKernelGGL(colsum_obj_kernel, dim3((cout + 31) / 32, nb), dim3(256), 0, s.st, o->g.d, o->g.ld, part, 256, cout, rows);
-        hipLaunchKernelGGL(colsum_obj_kernel, dim3((cout + 31) / 32, 1), dim3(256), 0, s.st, part, cout, s.gr(base + "conv.1.bias"), nb, cout, (long)nb, 1);
+        hipLaunchKernelGGL(colsum_obj_kernel, dim3((cout + 31) / 32, nbk), dim3(256), 0, s.st, o->g.d, o->g.ld, part, 256, cout, rows);
+        hipLaunchKernelGGL(colsum_obj_kernel, dim3((cout + 31) / 32, 1), dim3(256), 0, s.st, part, cout, s.gr(base + "conv.1.bias"), nbk, cout, (long)nbk, 1);
       }
     }
     s.grad_of(y);
-    if (s.live()) hipLaunchKernelGGL(upconv_gather_bwd_kernel, dim3(nblk((long)B * h * w * 9 * (cout / 4))), dim3(TB), 0, s.st, o->g.d, y->g.d, B, h, w, cout);
+    if (s.live())
+      for (int i = 0; i < nb; ++i)
+        hipLaunchKernelGGL(upconv_gather_bwd_kernel, dim3(nblk((long)li->B[i] * li->H[i] * li->W[i] * 9 * (cout / 4))), dim3(TB), 0, s.st,
+                           o->g.d + lo->off[i] * cout, y->g.d + li->off[i] * 9 * cout, li->B[i], li->H[i], li->W[i], cout);
     wgrad(s, p, y->g, s.gr(cw.name), nullptr);
     const bool acc = s.grad_of(x);
     dgrad(s, p, y->g, x->g, s.pf(cw.name), acc);
@@ -1119,65 +1274,91 @@ Act *upconv(Step &s, Act *x, const std::string &base, int cin, int cout) {
 void posenet_step(Step &s, const PoseNetIO &io) {
   Trainer &t = *s.t;
   const std::string C = CNN;
-  const int B = io.B, N = t.N, Npad = round_up(N, 128), rows = B * Npad;
+  int B = 0;
+  for (int i = 0; i < io.nb; ++i) B += io.B[i];
+  const int nb = io.nb, N = t.N, Npad = round_up(N, 128), rows = B * Npad;
   s.splitk_bytes = (size_t)32 << 20;
   s.splitk = static_cast<float *>(s.bytes(s.splitk_bytes));
   Step *sp = &s;
 
   // ---- colour branch (lib/extractors.py:114-124, lib/pspnet.py:64-77) ----
-  Act *img4 = s.act(B, io.H, io.W, 4);
-  if (s.live()) launch_nchw3_to_nhwc4(io.img, img4->v.d, B, io.H, io.W, s.st);
+  Lv limg;
+  for (int i = 0; i < nb; ++i) limg.push(io.B[i], io.H[i], io.W[i]);
+  Act *img4 = s.act(s.level(limg), 4);
+  if (s.live())
+    for (int i = 0; i < nb; ++i) launch_nchw3_to_nhwc4(io.img[i], img4->v.d + img4->lv->off[i] * 4, io.B[i], io.H[i], io.W[i], s.st);
   Act *stem = conv(s, img4, 4, ConvW{C + "feats.conv1.weight"}, 64, 7, 2, 3, 1, ACT_RELU, nullptr, nullptr, false);
-  Act *x = s.act(B, conv_out(stem->H, 3, 2, 1, 1), conv_out(stem->W, 3, 2, 1, 1), 64);
-  if (s.live()) launch_maxpool3s2(stem->v.d, x->v.d, B, stem->H, stem->W, 64, x->H, x->W, s.st);
-  s.tape.push_back([=]() {
-    Step &s = *sp;
-    s.grad_of(stem);
-    if (s.live()) s.fail(df_maxpool3s2_bwd(stem->v.d, x->g.d, stem->g.d, B, stem->H, stem->W, 64, x->H, x->W, s.st));
-  });
+  Lv lpool;
+  for (int i = 0; i < nb; ++i) lpool.push(io.B[i], conv_out(stem->lv->H[i], 3, 2, 1, 1), conv_out(stem->lv->W[i], 3, 2, 1, 1));
+  Act *x = s.act(s.level(lpool), 64);
+  {
+    const Lv *ls = stem->lv, *lx = x->lv;
+    if (s.live())
+      for (int i = 0; i < nb; ++i)
+        launch_maxpool3s2(stem->v.d + ls->off[i] * 64, x->v.d + lx->off[i] * 64, ls->B[i], ls->H[i], ls->W[i], 64, lx->H[i], lx->W[i], s.st);
+    Act *xp = x;
+    s.tape.push_back([=]() {
+      Step &s = *sp;
+      s.grad_of(stem);
+      if (s.live())
+        for (int i = 0; i < nb; ++i)
+          s.fail(df_maxpool3s2_bwd(stem->v.d + ls->off[i] * 64, xp->g.d + lx->off[i] * xp->g.ld, stem->g.d + ls->off[i] * 64, ls->B[i], ls->H[i], ls->W[i], 64,
+                                   lx->H[i], lx->W[i], s.st));
+    });
+  }
   int cin = 64;
   const int planes_of[4] = {64, 128, 256, 512}, stride_of[4] = {1, 2, 1, 1}, dil_of[4] = {1, 1, 2, 4};
-  Act *cat = nullptr;      // [B][h][w][2560]: the four pyramid priors then layer4's output (lib/pspnet.py:23)
+  Act *cat = nullptr;      // [rows][2560]: the four pyramid priors then layer4's output (lib/pspnet.py:23)
   for (int li = 1; li <= 4; ++li) {
     const int planes = planes_of[li - 1];
     const std::string base = C + "feats.layer" + std::to_string(li) + ".";
     x = basic_block(s, x, cin, base + "0.", planes, stride_of[li - 1], 1, cin != planes || stride_of[li - 1] != 1);
     Act *into = nullptr;
     if (li == 4) {          // the last block writes straight into its slot of the PSP concatenation
-      cat = s.act(B, x->H, x->W, 2560);
+      cat = s.act(x->lv, 2560);
       into = slice(s, cat, 2048, 512);
     }
     x = basic_block(s, x, planes, base + "1.", planes, 1, dil_of[li - 1], false, into);
     cin = planes;
   }
-  const int h = x->H, w = x->W;
-  // PSP module (lib/pspnet.py:20-24): pool -> 1x1 conv -> bilinear (align_corners=False) into the concat slots
+  const Lv *l8 = cat->lv;  // the 1/8-resolution level
+  // PSP module (lib/pspnet.py:20-24): pool -> 1x1 conv -> bilinear (align_corners=False) into the concat slots.  The pooled maps of
+  // every frame of every bucket sit in ONE set of stage blocks ([4][B*36][512], frames in bucket order): the four stage convolutions are
+  // single GEMMs; pooling and resampling (and their adjoints) run per bucket
   Act *feat = x;           // == cat[:, 2048:2560]
-  // all four pyramid levels in one launch (the inference engine's kernel: level i is the compact [B][sz][sz][512] block i of `pyr`)
   float *pyr = s.f((size_t)4 * B * 36 * 512);
-  if (s.live()) launch_psp_pool(feat->v.d, feat->v.ld, 0, pyr, B, h, w, 512, s.st);
-  for (int i = 0; i < 4; ++i) {
-    const int sz = i == 0 ? 1 : i == 1 ? 2 : i == 2 ? 3 : 6;
-    Act *pooled = s.act(B, sz, sz, 512, pyr + (size_t)i * B * 36 * 512, 512);
+  if (s.live())
+    for (int i = 0; i < nb; ++i)
+      launch_psp_pool(feat->v.d + l8->off[i] * feat->v.ld, feat->v.ld, 0, pyr, l8->B[i], l8->H[i], l8->W[i], 512, s.st, B, l8->b0[i]);
+  for (int si = 0; si < 4; ++si) {
+    const int sz = si == 0 ? 1 : si == 1 ? 2 : si == 2 ? 3 : 6;
+    Act *pooled = s.act((long)B * sz * sz, 512, pyr + (size_t)si * B * 36 * 512, 512);
     s.tape.push_back([=]() {
       Step &s = *sp;
       const bool acc = s.grad_of(feat);
       if (s.live())
-        hipLaunchKernelGGL(pool_bwd_kernel, dim3(nblk((long)B * h * w * 128)), dim3(TB), 0, s.st, pooled->g.d, feat->g.d, feat->g.ld, B, h, w, 128, sz, acc ? 1 : 0);
+        for (int i = 0; i < nb; ++i)
+          hipLaunchKernelGGL(pool_bwd_kernel, dim3(nblk((long)l8->B[i] * l8->H[i] * l8->W[i] * 128)), dim3(TB), 0, s.st,
+                             pooled->g.d + (size_t)l8->b0[i] * sz * sz * 512, feat->g.d + l8->off[i] * feat->g.ld, feat->g.ld, l8->B[i], l8->H[i], l8->W[i], 128, sz,
+                             acc ? 1 : 0);
     });
-    Act *z = conv(s, pooled, 512, ConvW{C + "psp.stages." + std::to_string(i) + ".1.weight"}, 512, 1, 1, 0, 1, ACT_NONE);
-    Act *prior = slice(s, cat, 512 * i, 512);
-    if (s.live()) hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(nblk((long)B * h * w * 128)), dim3(TB), 0, s.st, z->v.d, prior->v.d, prior->v.ld, B, sz, sz, 128, h, w, 0);
+    Act *z = conv(s, pooled, 512, ConvW{C + "psp.stages." + std::to_string(si) + ".1.weight"}, 512, 1, 1, 0, 1, ACT_NONE);
+    Act *prior = slice(s, cat, 512 * si, 512);
+    if (s.live())
+      for (int i = 0; i < nb; ++i)
+        hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(nblk((long)l8->B[i] * l8->H[i] * l8->W[i] * 128)), dim3(TB), 0, s.st, z->v.d + (size_t)l8->b0[i] * sz * sz * 512,
+                           prior->v.d + l8->off[i] * prior->v.ld, prior->v.ld, l8->B[i], sz, sz, 128, l8->H[i], l8->W[i], 0);
     s.tape.push_back([=]() {
       Step &s = *sp;
       s.grad_of(z);
       if (s.live())
-        hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)((long)B * sz * sz * 4)), dim3(TB), 0, s.st, cat->g.d + 512 * i, cat->g.ld, z->g.d, B, sz, sz, 128, h, w, 0);
+        for (int i = 0; i < nb; ++i)
+          hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)((long)l8->B[i] * sz * sz * 4)), dim3(TB), 0, s.st, cat->g.d + l8->off[i] * cat->g.ld + 512 * si,
+                             cat->g.ld, z->g.d + (size_t)l8->b0[i] * sz * sz * 512, l8->B[i], sz, sz, 128, l8->H[i], l8->W[i], 0);
     });
   }
   // the concat's gradient buffer is one allocation; layer4's output gradient is its last 512 channels
   s.tape.push_back([=]() {
-    Step &s = *sp;
     feat->g.d = cat->g.d + 2048;
     feat->g.ld = 2560;
     feat->gset = true;
@@ -1189,23 +1370,32 @@ void posenet_step(Step &s, const PoseNetIO &io) {
   Act *u2 = upconv(s, u1, C + "up_2.", 256, 64);
   if (io.dropout) u2 = dropout2d(s, u2, 0.15f, io.seed * 4 + 3);
   // up_3 + final 1x1 + LogSoftmax at the chosen pixels only (lib/network.py:98-102 reads nothing else)
-  Act *patch = s.act(rows, 1, 1, 576);
-  if (s.live()) launch_up3_patches(u2->v.d, io.choose, patch->v.d, B, u2->H, u2->W, N, Npad, s.st);
+  Act *patch = s.act((long)rows, 576);
+  const Lv *l2 = u2->lv;   // half resolution
+  if (s.live())
+    for (int i = 0; i < nb; ++i)
+      launch_up3_patches(u2->v.d + l2->off[i] * 64, io.choose + (size_t)l2->b0[i] * N, patch->v.d + (size_t)l2->b0[i] * Npad * 576, l2->B[i], l2->H[i], l2->W[i], N,
+                         Npad, s.st);
   s.tape.push_back([=]() {
     Step &s = *sp;
     s.grad_of(u2);
-    int4 *tab = reinterpret_cast<int4 *>(s.bytes((size_t)B * N * sizeof(int4)));
-    int *rowlist = reinterpret_cast<int *>(s.bytes((size_t)B * u2->H * N * sizeof(int)));
-    int *rowcnt = reinterpret_cast<int *>(s.bytes((size_t)B * u2->H * sizeof(int)));
-    if (s.live()) {
-      hipLaunchKernelGGL(up3_decode_kernel, dim3(nblk((long)B * N)), dim3(TB), 0, s.st, io.choose, tab, B, u2->H, u2->W, N);
-      hipLaunchKernelGGL(up3_rowlist_kernel, dim3(u2->H, B), dim3(TB), 0, s.st, tab, rowlist, rowcnt, u2->H, N);
-      hipLaunchKernelGGL(up3_patch_bwd_kernel, dim3((u2->W + TB / 16 - 1) / (TB / 16), u2->H, B), dim3(TB), 0, s.st, patch->g.d, tab, rowlist, rowcnt, u2->g.d,
-                         u2->H, u2->W, N, Npad);
+    for (int i = 0; i < nb; ++i) {
+      const int Bi = l2->B[i], h = l2->H[i], wd = l2->W[i];
+      const size_t mark = s.off;
+      int4 *tab = reinterpret_cast<int4 *>(s.bytes((size_t)Bi * N * sizeof(int4)));
+      int *rowlist = reinterpret_cast<int *>(s.bytes((size_t)Bi * h * N * sizeof(int)));
+      int *rowcnt = reinterpret_cast<int *>(s.bytes((size_t)Bi * h * sizeof(int)));
+      if (s.live()) {
+        hipLaunchKernelGGL(up3_decode_kernel, dim3(nblk((long)Bi * N)), dim3(TB), 0, s.st, io.choose + (size_t)l2->b0[i] * N, tab, Bi, h, wd, N);
+        hipLaunchKernelGGL(up3_rowlist_kernel, dim3(h, Bi), dim3(TB), 0, s.st, tab, rowlist, rowcnt, h, N);
+        hipLaunchKernelGGL(up3_patch_bwd_kernel, dim3((wd + TB / 16 - 1) / (TB / 16), h, Bi), dim3(TB), 0, s.st, patch->g.d + (size_t)l2->b0[i] * Npad * 576, tab,
+                           rowlist, rowcnt, u2->g.d + l2->off[i] * 64, h, wd, N, Npad);
+      }
+      s.off = mark;
     }
   });
   Act *z3 = conv(s, patch, 576, ConvW{C + "up_3.conv.1.weight", 0, C + "up_3.conv.1.bias", 0, C + "up_3.conv.2.weight"}, 64, 1, 1, 0, 1, ACT_PRELU);
-  Act *emb_pm = s.act(rows, 1, 1, 32);
+  Act *emb_pm = s.act((long)rows, 32);
   float *emb = io.emb ? io.emb : s.f((size_t)B * 32 * N);
   if (s.live()) {
     hipMemsetAsync(emb_pm->v.d, 0, (size_t)rows * 32 * sizeof(float), s.st);      // rows n >= N feed e_conv1: keep them finite
@@ -1217,15 +1407,15 @@ void posenet_step(Step &s, const PoseNetIO &io) {
     float *dlog = s.f((size_t)rows * 32);
     if (s.live()) s.fail(df_logsoftmax(emb_pm->g.d, emb_pm->v.d, dlog, rows, 32, 1, s.st));
     Act lg;
-    lg.B = rows; lg.C = 32; lg.v.d = nullptr; lg.v.ld = 32;
-    ConvParams f = base_params(z3, 64, s.p(C + "final.0.weight"), nullptr, &lg, 1, 1, 0, 1, ACT_NONE);
+    lg.lv = z3->lv; lg.C = 32; lg.v.d = nullptr; lg.v.ld = 32;
+    ConvParams f = flat_params(z3, 64, s.p(C + "final.0.weight"), nullptr, &lg, ACT_NONE);
     wgrad(s, f, View{dlog, 32}, s.gr(C + "final.0.weight"), s.gr(C + "final.0.bias"));
     s.grad_of(z3);
     dgrad(s, f, View{dlog, 32}, z3->g, s.pf(C + "final.0.weight"), false);
   });
 
   // ---- PoseNetFeat (lib/network.py:53-68) on point rows padded to Npad per frame: pf = [x1 64 | e1 64 | x2 128 | e2 128] ----
-  Act *pf = s.act(rows, 1, 1, 384);
+  Act *pf = s.act((long)rows, 384);
   Act *x1 = slice(s, pf, 0, 64), *e1 = slice(s, pf, 64, 64), *x2 = slice(s, pf, 128, 128), *e2 = slice(s, pf, 256, 128);
   if (s.live()) {
     hipMemsetAsync(pf->v.d, 0, (size_t)rows * 384 * sizeof(float), s.st);
@@ -1233,7 +1423,6 @@ void posenet_step(Step &s, const PoseNetIO &io) {
   }
   // every slice's gradient lives in ONE [rows][384] buffer, written first by head layer 1's data gradient
   auto pf_grad_views = [=]() {
-    Step &s = *sp;
     Act *sl[4] = {x1, e1, x2, e2};
     const int c0[4] = {0, 64, 128, 256};
     for (int i = 0; i < 4; ++i) { sl[i]->g.d = pf->g.d + c0[i]; sl[i]->g.ld = 384; sl[i]->gset = true; }
@@ -1253,12 +1442,10 @@ void posenet_step(Step &s, const PoseNetIO &io) {
   conv(s, x1, 64, ConvW{"feat.conv2.weight", 0, "feat.conv2.bias"}, 128, 1, 1, 0, 1, ACT_RELU, nullptr, x2);
   conv(s, e1, 64, ConvW{"feat.e_conv2.weight", 0, "feat.e_conv2.bias"}, 128, 1, 1, 0, 1, ACT_RELU, nullptr, e2);
   Act *pf2 = slice(s, pf, 128, 256);
-  s.tape.push_back([=]() {          // (runs after conv5's backward) nothing to do: pf2's gradient view was set by pf_grad_views
-  });
   Act *x5 = conv(s, pf2, 256, ConvW{"feat.conv5.weight", 0, "feat.conv5.bias"}, 512, 1, 1, 0, 1, ACT_RELU);
   // conv6 + ReLU; its mean over the points (AvgPool1d) from the GEMM's fused column sums
-  Act *x6 = s.act(rows, 1, 1, 1024);
-  ConvParams p6 = base_params(x5, 512, s.p("feat.conv6.weight"), s.p("feat.conv6.bias"), x6, 1, 1, 0, 1, ACT_RELU);
+  Act *x6 = s.act((long)rows, 1024);
+  ConvParams p6 = flat_params(x5, 512, s.p("feat.conv6.weight"), s.p("feat.conv6.bias"), x6, ACT_RELU);
   p6.rows_per_group = Npad; p6.rows_valid = N;
   int prow;
   {
@@ -1268,7 +1455,7 @@ void posenet_step(Step &s, const PoseNetIO &io) {
   }
   float *partial = s.f((size_t)prow * 1024);
   p6.colsum = partial;
-  if (s.live()) s.fail(launch_conv(p6, s.st));
+  s.gemm(GK_FWD, p6);
   float *apx = s.f((size_t)B * 1024), *dap = s.f((size_t)B * 1024);
   if (s.live()) launch_colsum_finish(partial, prow / B, apx, B, 1024, N, s.st);
   s.tape.push_back([=]() {
@@ -1285,10 +1472,10 @@ void posenet_step(Step &s, const PoseNetIO &io) {
   // ---- heads (lib/network.py:107-131): layer 1 with the global feature folded into a per-frame bias, towers stacked r, t, c ----
   float *gbias = s.f((size_t)B * 1920), *s1 = s.f((size_t)B * 1920);
   if (s.live()) launch_fc_rows(apx, 1024, 0, s.p("head1.wg"), s.p("head1.bias"), gbias, 1920, B, 1024, 1920, 1, 0, s.st);
-  Act *h1 = s.act(rows, 1, 1, 1920);
-  ConvParams p1 = base_params(pf, 384, s.p("head1.wpt"), gbias, h1, 1, 1, 0, 1, ACT_RELU);
+  Act *h1 = s.act((long)rows, 1920);
+  ConvParams p1 = flat_params(pf, 384, s.p("head1.wpt"), gbias, h1, ACT_RELU);
   p1.rows_per_group = Npad; p1.rows_valid = N; p1.bias_group_ld = 1920;
-  if (s.live()) s.fail(launch_conv(p1, s.st));
+  s.gemm(GK_FWD, p1);
   s.tape.push_back([=]() {
     Step &s = *sp;
     launch_act_bwd(s, h1, ACT_RELU, nullptr, nullptr);
@@ -1307,15 +1494,15 @@ void posenet_step(Step &s, const PoseNetIO &io) {
       q.wgt = s.pf("head1.wg");
       q.out = dap; q.Cout = 1024; q.out_ld = 1024;
       q.splitk_ws = s.splitk; q.splitk_ws_bytes = s.splitk_bytes;
-      if (s.live()) s.fail(launch_conv(q, s.st));
+      s.gemm(GK_DGRAD, q);
     }
   });
-  Act *h2 = s.act(rows, 1, 1, 768), *h3 = s.act(rows, 1, 1, 384);
+  Act *h2 = s.act((long)rows, 768), *h3 = s.act((long)rows, 384);
   auto towers = [&](Act *in, int cin_t, Act *out, int cout_t, const std::string &wname, const std::string &bname) {
-    ConvParams p = base_params(in, cin_t, s.p(wname), s.p(bname), out, 1, 1, 0, 1, ACT_RELU);
+    ConvParams p = flat_params(in, cin_t, s.p(wname), s.p(bname), out, ACT_RELU);
     p.Cout = cout_t;
     p.zcount = 3; p.z_in_coff = cin_t; p.z_wgt = (long)cout_t * cin_t; p.z_bias = cout_t; p.z_out_coff = cout_t;
-    if (s.live()) s.fail(launch_conv(p, s.st));
+    s.gemm(GK_FWD, p);
     s.tape.push_back([=]() {
       Step &s = *sp;
       launch_act_bwd(s, out, ACT_RELU, nullptr, nullptr);
@@ -1389,13 +1576,13 @@ void refiner_step(Step &s, const RefinerIO &io) {
   Step *sp = &s;
   s.splitk_bytes = (size_t)8 << 20;
   s.splitk = static_cast<float *>(s.bytes(s.splitk_bytes));
-  Act *emb_pm = s.act(rows, 1, 1, 32);
+  Act *emb_pm = s.act((long)rows, 32);
   if (s.live()) {
     hipMemsetAsync(emb_pm->v.d, 0, (size_t)rows * 32 * sizeof(float), s.st);
     launch_emb_to_pm(io.emb, emb_pm->v.d, B, N, Npad, s.st);
   }
   // pointfeat_3 = [x1 64 | e1 64 | x2 128 | e2 128] (lib/network.py:160-163)
-  Act *pf = s.act(rows, 1, 1, 384);
+  Act *pf = s.act((long)rows, 384);
   Act *x1 = slice(s, pf, 0, 64), *e1 = slice(s, pf, 64, 64), *x2 = slice(s, pf, 128, 128), *e2 = slice(s, pf, 256, 128);
   if (s.live()) {
     hipMemsetAsync(pf->v.d, 0, (size_t)rows * 384 * sizeof(float), s.st);
@@ -1416,10 +1603,10 @@ void refiner_step(Step &s, const RefinerIO &io) {
   conv(s, x1, 64, ConvW{"feat.conv2.weight", 0, "feat.conv2.bias"}, 128, 1, 1, 0, 1, ACT_RELU, nullptr, x2);
   conv(s, e1, 64, ConvW{"feat.e_conv2.weight", 0, "feat.e_conv2.bias"}, 128, 1, 1, 0, 1, ACT_RELU, nullptr, e2);
   // conv5 reads all 384 channels: its data gradient is the first writer of pf's gradient buffer
-  Act *x5 = s.act(rows, 1, 1, 512);
+  Act *x5 = s.act((long)rows, 512);
   {
-    ConvParams p5 = base_params(pf, 384, s.p("feat.conv5.weight"), s.p("feat.conv5.bias"), x5, 1, 1, 0, 1, ACT_RELU);
-    if (s.live()) s.fail(launch_conv(p5, s.st));
+    ConvParams p5 = flat_params(pf, 384, s.p("feat.conv5.weight"), s.p("feat.conv5.bias"), x5, ACT_RELU);
+    s.gemm(GK_FWD, p5);
     s.tape.push_back([=]() {
       Step &s = *sp;
       launch_act_bwd(s, x5, ACT_RELU, nullptr, nullptr);
@@ -1431,8 +1618,8 @@ void refiner_step(Step &s, const RefinerIO &io) {
       for (int i = 0; i < 4; ++i) { sl[i]->g.d = pf->g.d + c0[i]; sl[i]->g.ld = 384; sl[i]->gset = true; }
     });
   }
-  Act *x6 = s.act(rows, 1, 1, 1024);
-  ConvParams p6 = base_params(x5, 512, s.p("feat.conv6.weight"), s.p("feat.conv6.bias"), x6, 1, 1, 0, 1, ACT_RELU);
+  Act *x6 = s.act((long)rows, 1024);
+  ConvParams p6 = flat_params(x5, 512, s.p("feat.conv6.weight"), s.p("feat.conv6.bias"), x6, ACT_RELU);
   p6.rows_per_group = Npad; p6.rows_valid = N;
   int prow;
   {
@@ -1442,8 +1629,8 @@ void refiner_step(Step &s, const RefinerIO &io) {
   }
   float *partial = s.f((size_t)prow * 1024);
   p6.colsum = partial;
-  if (s.live()) s.fail(launch_conv(p6, s.st));
-  Act *ap = s.act(B, 1, 1, 1024);
+  s.gemm(GK_FWD, p6);
+  Act *ap = s.act((long)B, 1024);
   if (s.live()) launch_colsum_finish(partial, prow / B, ap->v.d, B, 1024, N, s.st);
   s.tape.push_back([=]() {
     Step &s = *sp;
@@ -1456,10 +1643,8 @@ void refiner_step(Step &s, const RefinerIO &io) {
     dgrad(s, f, x6->g, x5->g, s.pf("feat.conv6.weight"), false);
   });
   // FC towers 1024 -> 512 -> 128 (lib/network.py:191-196), one row per frame; f2 = [r 128 | t 128]
-  Act *f1 = s.act(B, 1, 1, 1024), *f2 = s.act(B, 1, 1, 256);
+  Act *f1 = s.act((long)B, 1024), *f2 = s.act((long)B, 256);
   Act *f1r = slice(s, f1, 0, 512), *f1t = slice(s, f1, 512, 512), *f2r = slice(s, f2, 0, 128), *f2t = slice(s, f2, 128, 128);
-  s.tape.push_back([=]() {           // ap's gradient: r tower writes, t tower accumulates (conv() handles it through gset)
-  });
   conv(s, ap, 1024, ConvW{"conv1_r.weight", 0, "conv1_r.bias"}, 512, 1, 1, 0, 1, ACT_RELU, nullptr, f1r);
   conv(s, ap, 1024, ConvW{"conv1_t.weight", 0, "conv1_t.bias"}, 512, 1, 1, 0, 1, ACT_RELU, nullptr, f1t);
   conv(s, f1r, 512, ConvW{"conv2_r.weight", 0, "conv2_r.bias"}, 128, 1, 1, 0, 1, ACT_RELU, nullptr, f2r);
@@ -1535,6 +1720,7 @@ extern "C" void df_trainer_destroy(df_trainer *h) {
   if (t->wflip) hipFree(t->wflip);
   if (t->wino_buf) hipFree(t->wino_buf);
   if (t->flip_tab) hipFree(t->flip_tab);
+  for (auto e : t->ev) hipEventDestroy(e);
   delete t;
 }
 
@@ -1586,19 +1772,63 @@ extern "C" int df_trainer_unpack_param(const df_trainer *h, const char *key, con
   return relayout(*as_trainer(h), key, dst, const_cast<float *>(flat), 1, to_stream(stream));
 }
 
-extern "C" size_t df_posenet_train_workspace_bytes(const df_trainer *h, int B, int H, int W, int M) {
-  if (!h || as_trainer(h)->kind != 0 || B <= 0 || H < 8 || W < 8 || M <= 0) return 0;
+static int posenet_buckets_ok(const Trainer *t, int nb, const int *B, const int *H, const int *W, int M, const char *what) {
+  if (!t || t->kind != 0) return set_error(DF_ERR_ARG, "%s: not a PoseNet trainer", what);
+  if (nb <= 0 || nb > 4096 || !B || !H || !W || M <= 0) return set_error(DF_ERR_ARG, "%s: need 1..4096 buckets with B / H / W arrays and M >= 1", what);
+  long tot = 0;
+  for (int i = 0; i < nb; ++i) {
+    if (B[i] <= 0 || H[i] < 8 || W[i] < 8 || H[i] > DF_MAX_CROP || W[i] > DF_MAX_CROP)
+      return set_error(DF_ERR_ARG, "%s: bucket %d: need B >= 1 and 8 <= H, W <= %d (got %d, %d, %d)", what, i, DF_MAX_CROP, B[i], H[i], W[i]);
+    tot += B[i];
+  }
+  if (tot > 65535) return set_error(DF_ERR_ARG, "%s: too many frames in one pass (%ld)", what, tot);
+  return DF_OK;
+}
+
+extern "C" size_t df_posenet_train_multi_workspace_bytes(const df_trainer *h, int nb, const int *B, const int *H, const int *W, int M) {
+  if (!h || posenet_buckets_ok(as_trainer(h), nb, B, H, W, M, "posenet_train_workspace_bytes") != DF_OK) return 0;
   Trainer &t = *const_cast<Trainer *>(as_trainer(h));
-  const std::vector<int> key{B, H, W, M};
+  std::vector<int> key{nb, M};
+  for (int i = 0; i < nb; ++i) { key.push_back(B[i]); key.push_back(H[i]); key.push_back(W[i]); }
   auto it = t.ws_cache.find(key);
   if (it != t.ws_cache.end()) return it->second;
   Step s{&t, nullptr, true, nullptr};
   PoseNetIO io{};
-  io.B = B; io.H = H; io.W = W; io.M = M; io.dropout = 1;
+  io.nb = nb; io.B = B; io.H = H; io.W = W; io.M = M; io.dropout = 1;
   posenet_step(s, io);
   if (t.ws_cache.size() > 4096) t.ws_cache.clear();
   t.ws_cache[key] = s.peak;
   return s.peak;
+}
+
+extern "C" size_t df_posenet_train_workspace_bytes(const df_trainer *h, int B, int H, int W, int M) {
+  return df_posenet_train_multi_workspace_bytes(h, 1, &B, &H, &W, M);
+}
+
+extern "C" int df_posenet_train_step_multi(df_trainer *h, const float *flat_param, float *flat_grad, int64_t param_version, int nb, const int *B,
+                                           const int *H, const int *W, const float *const *img, const float *cloud, const int64_t *choose,
+                                           const int64_t *obj, const float *target, const float *model_points, int M, const int *symmetric_host,
+                                           float w, int dropout, unsigned seed, float *loss_out, float *dis_out, float *new_points,
+                                           float *new_target, float *out_r, float *out_t, float *out_c, float *emb, void *ws, size_t ws_bytes,
+                                           df_stream_t stream) {
+  if (!h) return set_error(DF_ERR_ARG, "posenet_train_step: null handle");
+  int rc = posenet_buckets_ok(as_trainer(h), nb, B, H, W, M, "posenet_train_step");
+  if (rc != DF_OK) return rc;
+  if (!flat_param || !flat_grad || !img || !cloud || !choose || !obj || !target || !model_points || !loss_out || !dis_out || !ws)
+    return set_error(DF_ERR_ARG, "posenet_train_step: null pointer");
+  for (int i = 0; i < nb; ++i)
+    if (!img[i]) return set_error(DF_ERR_ARG, "posenet_train_step: bucket %d: null image pointer", i);
+  Trainer &t = *as_trainer(h);
+  if (df_posenet_train_multi_workspace_bytes(h, nb, B, H, W, M) > ws_bytes) return set_error(DF_ERR_WORKSPACE, "posenet_train_step: workspace too small");
+  rc = check_flips(t, flat_param, (long)param_version, to_stream(stream));
+  if (rc != DF_OK) return rc;
+  Step s{&t, to_stream(stream), false, static_cast<char *>(ws)};
+  s.cap = ws_bytes; s.P = flat_param; s.G = flat_grad;
+  PoseNetIO io{nb, B, H, W, img, M, cloud, target, model_points, choose, obj, symmetric_host, w, dropout, seed, loss_out, dis_out, new_points, new_target,
+               out_r, out_t, out_c, emb};
+  posenet_step(s, io);
+  if (s.err != DF_OK) return s.err;
+  return check_launch("posenet_train_step");
 }
 
 extern "C" int df_posenet_train_step(df_trainer *h, const float *flat_param, float *flat_grad, int64_t param_version, int B, int H, int W,
@@ -1606,21 +1836,39 @@ extern "C" int df_posenet_train_step(df_trainer *h, const float *flat_param, flo
                                      const float *model_points, int M, const int *symmetric_host, float w, int dropout, unsigned seed,
                                      float *loss_out, float *dis_out, float *new_points, float *new_target, float *out_r, float *out_t,
                                      float *out_c, float *emb, void *ws, size_t ws_bytes, df_stream_t stream) {
-  if (!h || as_trainer(h)->kind != 0) return set_error(DF_ERR_ARG, "posenet_train_step: not a PoseNet trainer");
-  if (B <= 0 || H < 8 || W < 8 || M <= 0 || H > DF_MAX_CROP || W > DF_MAX_CROP) return set_error(DF_ERR_ARG, "posenet_train_step: need B >= 1, 8 <= H, W <= %d, M >= 1", DF_MAX_CROP);
-  if (!flat_param || !flat_grad || !img || !cloud || !choose || !obj || !target || !model_points || !loss_out || !dis_out || !ws)
-    return set_error(DF_ERR_ARG, "posenet_train_step: null pointer");
-  Trainer &t = *as_trainer(h);
-  if (df_posenet_train_workspace_bytes(h, B, H, W, M) > ws_bytes) return set_error(DF_ERR_WORKSPACE, "posenet_train_step: workspace too small");
-  int rc = check_flips(t, flat_param, (long)param_version, to_stream(stream));
-  if (rc != DF_OK) return rc;
-  Step s{&t, to_stream(stream), false, static_cast<char *>(ws)};
-  s.cap = ws_bytes; s.P = flat_param; s.G = flat_grad;
-  PoseNetIO io{B, H, W, M, img, cloud, target, model_points, choose, obj, symmetric_host, w, dropout, seed, loss_out, dis_out, new_points, new_target,
-               out_r, out_t, out_c, emb};
-  posenet_step(s, io);
-  if (s.err != DF_OK) return s.err;
-  return check_launch("posenet_train_step");
+  return df_posenet_train_step_multi(h, flat_param, flat_grad, param_version, 1, &B, &H, &W, &img, cloud, choose, obj, target, model_points, M,
+                                     symmetric_host, w, dropout, seed, loss_out, dis_out, new_points, new_target, out_r, out_t, out_c, emb, ws, ws_bytes,
+                                     stream);
+}
+
+// Profile of the MFMA launches of the steps run on this handle since df_trainer_profile(h, 1): HIP events bracket every forward /
+// data-gradient / weight-gradient GEMM on the launch stream; the FLOPs are those the launches EXECUTE (2 M N K of the shapes really run:
+// low-resolution up-convolutions, folded head layer 1, chosen-pixel up_3, F(4x4,3x3)-domain products), not the reference graph's.
+extern "C" int df_trainer_profile(df_trainer *h, int enable) {
+  if (!h) return set_error(DF_ERR_ARG, "trainer_profile: null handle");
+  Trainer *t = as_trainer(h);
+  t->profiling = enable != 0;
+  t->ev_used = 0;
+  t->ev_kind.clear();
+  t->ev_flops.clear();
+  return DF_OK;
+}
+
+// after a stream sync: per kind (0 forward, 1 data gradient, 2 weight gradient) the summed launch durations (ms), executed FLOPs, launches
+extern "C" int df_trainer_profile_read(df_trainer *h, double *ms3, double *flops3, int *launches3) {
+  if (!h || !ms3 || !flops3 || !launches3) return set_error(DF_ERR_ARG, "trainer_profile_read: null pointer");
+  Trainer *t = as_trainer(h);
+  for (int k = 0; k < 3; ++k) { ms3[k] = 0; flops3[k] = 0; launches3[k] = 0; }
+  for (size_t i = 0; i + 1 < t->ev_used; i += 2) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, t->ev[i], t->ev[i + 1]) != hipSuccess) return set_error(DF_ERR_LAUNCH, "trainer_profile_read: events not complete");
+    const int k = t->ev_kind[i / 2];
+    ms3[k] += ms; flops3[k] += t->ev_flops[i / 2]; launches3[k] += 1;
+  }
+  t->ev_used = 0;
+  t->ev_kind.clear();
+  t->ev_flops.clear();
+  return DF_OK;
 }
 
 extern "C" size_t df_refiner_train_workspace_bytes(const df_trainer *h, int B, int M) {

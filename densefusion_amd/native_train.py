@@ -152,6 +152,76 @@ class NativeTrainer:
         _lib.check(st, "posenet_train_step")
         return out
 
+    # ---- a window of frames of different crop sizes as ONE pass (df_posenet_train_step_multi) ----
+    def step_posenet_multi(self, imgs, cloud, choose, obj, target, model_points, symmetric, w, dropout=True, seed=None, want_pred=False,
+                           graph_safe=False):
+        """``imgs``: list of ``[B_i,3,H_i,W_i]`` tensors, one per crop-size bucket; every other argument as in ``step_posenet`` with the
+        frames of all buckets concatenated in bucket order (``sum B_i`` frames).  Per-point layers, 1x1 convolutions, Winograd-domain
+        products and every weight gradient run once over all buckets; the gradient added to ``.grad`` is the sum of the frames'
+        one-per-pass gradients up to fp32 summation order."""
+        assert self.kind == POSENET
+        f32 = lambda t: t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        imgs = [f32(i) for i in imgs]
+        cloud, target, model_points = f32(cloud), f32(target), f32(model_points)
+        nb = len(imgs)
+        Bs = [int(i.shape[0]) for i in imgs]
+        B = sum(Bs)
+        N, M = self.num_points, target.shape[-2]
+        if nb == 0 or any(i.dim() != 4 or i.shape[1] != 3 for i in imgs) or cloud.shape != (B, N, 3) or target.numel() != B * M * 3 \
+                or model_points.numel() != B * M * 3:
+            raise RuntimeError(f"step_posenet_multi: need images [B_i,3,H_i,W_i], cloud [{B},{N},3] and target / model_points [{B},M,3]")
+        choose = choose.to(device=self.device, dtype=torch.int64).reshape(B, N).contiguous()
+        obj = obj.to(device=self.device, dtype=torch.int64).reshape(B).contiguous()
+        dev = self.device
+        out = dict(loss=torch.empty(B, device=dev), dis=torch.empty(B, device=dev), new_points=torch.empty(B, N, 3, device=dev),
+                   new_target=torch.empty(B, M, 3, device=dev), emb=torch.empty(B, 32, N, device=dev))
+        if want_pred:
+            out.update(pred_r=torch.empty(B, N, 4, device=dev), pred_t=torch.empty(B, N, 3, device=dev), pred_c=torch.empty(B, N, 1, device=dev))
+        self._calls += 1
+        if seed is None:
+            seed = (int(torch.initial_seed() % 100003) * 7919 + self._calls + self._salt) & 0x3FFFFFFF
+        P = lambda k: out[k].data_ptr() if k in out else None
+        arr = ctypes.c_int * nb
+        cB, cH, cW = arr(*Bs), arr(*[int(i.shape[2]) for i in imgs]), arr(*[int(i.shape[3]) for i in imgs])
+        cimg = (ctypes.c_void_p * nb)(*[i.data_ptr() for i in imgs])
+        L = _lib.lib()
+        with _lib.device_guard(dev):
+            ws = self._workspace(L.df_posenet_train_multi_workspace_bytes(self._h, nb, cB, cH, cW, M))
+            st = L.df_posenet_train_step_multi(self._h, self.data.data_ptr(), self.grad.data_ptr(), -1 if graph_safe else self.version, nb, cB, cH, cW, cimg,
+                                               cloud.data_ptr(), choose.data_ptr(), obj.data_ptr(), target.data_ptr(), model_points.data_ptr(), M,
+                                               self._sym(symmetric, B), float(w), int(bool(dropout)), int(seed) & 0xFFFFFFFF,
+                                               P("loss"), P("dis"), P("new_points"), P("new_target"), P("pred_r"), P("pred_t"), P("pred_c"), P("emb"),
+                                               ws.data_ptr(), ws.numel(), _lib.current_stream())
+        _lib.check(st, "posenet_train_step_multi")
+        return out
+
+    def step_posenet_window(self, frames, w, dropout=True, seed=None):
+        """``frames``: list of dicts / tuples ``(img [3,H,W], cloud [N,3], choose [N]|[1,N], obj [1], target [M,3], model_points [M,3], symmetric)``
+        of ANY crop sizes: buckets them by (H, W) and runs them as one multi-bucket pass.  Returns (out, order): the step's outputs and, for
+        every output row, the index of its frame in ``frames``."""
+        keys = ("img", "cloud", "choose", "obj", "target", "model_points", "symmetric")
+        fr = [f if isinstance(f, dict) else dict(zip(keys, f)) for f in frames]
+        by_size = {}
+        for j, f in enumerate(fr):
+            by_size.setdefault((int(f["img"].shape[-2]), int(f["img"].shape[-1])), []).append(j)
+        order = [j for idxs in by_size.values() for j in idxs]
+        N = self.num_points
+        imgs = [torch.stack([fr[j]["img"].reshape(3, *hw) for j in idxs]) for hw, idxs in by_size.items()]
+        cat = lambda k, shape: torch.stack([fr[j][k].reshape(shape) for j in order])
+        out = self.step_posenet_multi(imgs, cat("cloud", (N, 3)), cat("choose", (N,)), cat("obj", (1,)), cat("target", (-1, 3)), cat("model_points", (-1, 3)),
+                                      [bool(fr[j]["symmetric"]) for j in order], w, dropout=dropout, seed=seed)
+        return out, order
+
+    # ---- executed-FLOP profile of the step's MFMA launches (df_trainer_profile) ----
+    def profile(self, enable=True):
+        _lib.check(_lib.lib().df_trainer_profile(self._h, int(bool(enable))), "trainer_profile")
+
+    def profile_read(self):
+        """After a device sync: {kind: (ms, executed FLOPs, launches)} for kind in fwd / dgrad / wgrad since the last read."""
+        ms, fl, n = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int * 3)()
+        _lib.check(_lib.lib().df_trainer_profile_read(self._h, ms, fl, n), "trainer_profile_read")
+        return {k: (ms[i], fl[i], n[i]) for i, k in enumerate(("fwd", "dgrad", "wgrad"))}
+
     # ---- PoseRefineNet + Loss_refine (tools/train.py:156-159) ----
     def step_refiner(self, points, emb, obj, target, model_points, symmetric, graph_safe=False):
         """One refine iteration: points [B,N,3] (in the current pose's frame), emb [B,32,N], target / model_points [B,M,3]

@@ -296,6 +296,26 @@ int df_posenet_train_step(df_trainer *t, const float *flat_param, float *flat_gr
                           const float *model_points, int M, const int *symmetric_host, float w, int dropout, unsigned seed,
                           float *loss_out, float *dis_out, float *new_points, float *new_target, float *out_r, float *out_t,
                           float *out_c, float *emb, void *ws, size_t ws_bytes, df_stream_t stream);
+/* A window of frames of DIFFERENT crop sizes as one pass (what real data gives: the reference trains on whatever crop each frame has,
+ * tools/train.py:131-176): nb crop-size buckets, bucket i = B[i] frames of H[i] x W[i] with their images at img[i] ([B_i][3][H_i][W_i],
+ * device; the B / H / W / img arrays are HOST arrays); every other per-frame tensor (cloud, choose, obj, target, model_points, symmetric_host,
+ * the outputs) is concatenated in bucket order, sum B frames.  Per-point layers, 1x1 convolutions, the F(4x4,3x3)-domain products and every
+ * weight / bias gradient run ONCE over the rows of all buckets; direct k x k convolutions and the resampling kernels run per bucket.  The
+ * gradient added to flat_grad equals the sum of the frames' one-per-pass gradients up to fp32 summation order (<= 1e-6 of each tensor's
+ * scale; the order itself is fixed: bit-reproducible).  df_posenet_train_step is the one-bucket case. */
+size_t df_posenet_train_multi_workspace_bytes(const df_trainer *t, int nb, const int *B, const int *H, const int *W, int M);
+int df_posenet_train_step_multi(df_trainer *t, const float *flat_param, float *flat_grad, int64_t param_version, int nb, const int *B,
+                                const int *H, const int *W, const float *const *img, const float *cloud, const int64_t *choose,
+                                const int64_t *obj, const float *target, const float *model_points, int M, const int *symmetric_host,
+                                float w, int dropout, unsigned seed, float *loss_out, float *dis_out, float *new_points,
+                                float *new_target, float *out_r, float *out_t, float *out_c, float *emb, void *ws, size_t ws_bytes,
+                                df_stream_t stream);
+/* Per-launch timing of a trainer's MFMA launches (HIP events on the step's stream; measurement only).  df_trainer_profile(t, 1) arms
+ * it; after the stream has been synchronised df_trainer_profile_read fills, per kind (0 forward, 1 data gradient, 2 weight gradient), the
+ * summed launch durations in ms, the FLOPs the launches EXECUTE (2 M N K of the shapes really run, not the reference graph's) and the
+ * launch counts since arming, and re-arms. */
+int df_trainer_profile(df_trainer *t, int enable);
+int df_trainer_profile_read(df_trainer *t, double *ms3, double *flops3, int *launches3);
 size_t df_refiner_train_workspace_bytes(const df_trainer *t, int B, int M);
 int df_refiner_train_step(df_trainer *t, const float *flat_param, float *flat_grad, int64_t param_version, int B, const float *points,
                           const float *emb, const int64_t *obj, const float *target, const float *model_points, int M,

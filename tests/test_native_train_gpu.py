@@ -370,3 +370,69 @@ def test_refiner_step_at_the_ycb_refine_mesh_size():
     _close(out["new_points"], torch.cat(want_np), 1e-4, "new_points"); _close(out["new_target"], torch.cat(want_nt), 1e-4, "new_target")
     for key, g in tr.grad_dict().items():
         _close(g, psd[key].grad, 2e-3, key)
+
+
+def test_a_window_of_mixed_crop_sizes_as_one_pass_equals_the_sum_of_its_one_frame_passes():
+    """df_posenet_train_step_multi: frames of DIFFERENT crop sizes in one pass (what real data gives, tools/train.py:131-176 of the
+    reference trains on whatever crop each frame has).  Per parameter tensor, the gradient of the window equals the sum of the
+    frames' bs = 1 passes up to fp32 summation order: <= 2e-5 of the tensor's largest gradient (NOT bit-identical: one contraction over
+    all frames' pixels adds in another order than frame-by-frame accumulation; measured 1e-7 .. 3e-6); per-frame outputs
+    (loss, dis, re-centred clouds) likewise.  Two identical multi-bucket passes are bit-identical, dropout on.  Covers a bucket with two
+    frames, symmetric and plain objects, a crop the F(4x4,3x3) route takes (160 x 160) and ones it does not."""
+    K, N, M = 3, 128, 60
+    sizes = [(40, 80), (160, 160), (80, 80), (40, 80), (120, 160)]
+    sd = synth.make_state_dict(synth.posenet_spec(K), 23)
+    objs = [synth.make_object(900 + i, h, w, N, K, num_points_mesh=M) for i, (h, w) in enumerate(sizes)]
+    for i, o in enumerate(objs):
+        o["obj"][0] = i % K
+    frames = [dict(img=torch.from_numpy(o["img"]).to(DEV), cloud=torch.from_numpy(o["cloud"]).to(DEV), choose=torch.from_numpy(o["choose"]).to(DEV),
+                   obj=torch.from_numpy(o["obj"]).to(DEV), target=torch.from_numpy(o["target"]).to(DEV), model_points=torch.from_numpy(o["model_points"]).to(DEV),
+                   symmetric=int(o["obj"][0]) == 1) for o in objs]
+    tr = _trainer("posenet", N, K, sd)
+    out, order = tr.step_posenet_window(frames, 0.015, dropout=False)
+    assert sorted(order) == list(range(len(frames))) and order[:2] == [0, 3]          # the two 40 x 80 frames share a bucket
+    g_multi = tr.grad_dict()
+    flat_multi = tr.grad.clone()
+    tr.zero_grad()
+    for row, j in enumerate(order):
+        f = frames[j]
+        o1 = tr.step_posenet(f["img"][None], f["cloud"][None], f["choose"].reshape(1, -1), f["obj"].reshape(1), f["target"][None], f["model_points"][None],
+                             [f["symmetric"]], 0.015, dropout=False)
+        for k in ("loss", "dis", "new_points", "new_target", "emb"):
+            _close(out[k][row:row + 1], o1[k], 2e-5, k)
+    g_single = tr.grad_dict()
+    worst = 0.0
+    for k, v in g_single.items():
+        if "classifier" in k:
+            assert float(g_multi[k].abs().max()) == 0.0          # dead weights (lib/pspnet.py:58-62) receive no gradient
+            continue
+        scale = max(float(v.abs().max()), 1e-12)
+        err = float((g_multi[k] - v).abs().max()) / scale
+        worst = max(worst, err)
+        assert err <= 2e-5, f"{k}: window vs sum of one-frame passes {err:.2e} of the tensor's scale"
+    print(f"mixed window vs one-frame passes: worst per-tensor deviation {worst:.2e} of scale")
+    _close(flat_multi, tr.grad, 2e-5, "flat gradient buffer")
+    runs = []
+    for _ in range(2):
+        tr.zero_grad()
+        tr.step_posenet_window(frames, 0.015, dropout=True, seed=5)
+        runs.append(tr.grad.clone())
+    assert torch.equal(runs[0], runs[1]) and float(runs[0].abs().sum()) > 0
+
+
+def test_trainer_profile_reports_executed_flops_per_kind():
+    K, N, M = 3, 128, 60
+    sd = synth.make_state_dict(synth.posenet_spec(K), 29)
+    o = synth.make_object(950, 80, 80, N, K, num_points_mesh=M)
+    f = _frames([o])
+    tr = _trainer("posenet", N, K, sd)
+    tr.profile(True)
+    tr.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], [False], 0.015, dropout=False)
+    torch.cuda.synchronize()
+    prof = tr.profile_read()
+    tr.profile(False)
+    assert set(prof) == {"fwd", "dgrad", "wgrad"}
+    for kind, (ms, fl, n) in prof.items():
+        assert ms > 0 and fl > 0 and n > 10, (kind, ms, fl, n)
+    # the weight gradients contract exactly the forward launches' shapes except the Winograd-domain ones (fewer multiplies forward)
+    assert prof["wgrad"][1] >= prof["fwd"][1] * 0.9

@@ -84,6 +84,13 @@ def build_parser():
                     help="PoseNet phase, native step: passes of one accumulation window run on this many concurrent lanes (own HIP stream, "
                          "host thread, workspace and gradient buffer each; gradients summed in lane order): bs = 1 passes fill a fraction "
                          "of the chip, so independent frames overlap.  1 = one pass at a time")
+    ap.add_argument("--passes", type=str, default="window", choices=["window", "lanes"],
+                    help="PoseNet phase, native step.  window (default): the frames of an accumulation window, whatever their crop sizes, run as ONE "
+                         "multi-bucket pass (df_posenet_train_step_multi: per-point layers, 1x1 / Winograd-domain products and every weight gradient "
+                         "once over all frames); lanes: one pass per --frames_per_pass frames of equal size, spread over --lanes concurrent lanes")
+    ap.add_argument("--window_pixels", type=int, default=1 << 21,
+                    help="--passes window: a window whose crops add up to more pixels than this is cut into several passes (bounds the workspace: "
+                         "about 4.6 KB per crop pixel)")
     ap.add_argument("--autograd_tape", action="store_true",
                     help="train through the per-layer autograd Functions of round 2 (lib/train_graph.py) instead of the native step "
                          "(csrc/train.hip: forward + loss + backward of a pass in one library call); same gradients, several times slower")
@@ -206,7 +213,7 @@ def main(argv=None):
         native["refiner"].load_state_dict(refiner.state_dict())
 
     lanes = None
-    if native and opt.lanes > 1:
+    if native and opt.lanes > 1 and opt.passes == "lanes":
         from densefusion_amd.native_train import Lanes
         lanes = Lanes(native["posenet"], opt.lanes)
 
@@ -289,6 +296,29 @@ def main(argv=None):
             out = (lane or native["refiner"]).step_refiner(new_points, emb, idx, new_target, model_points, sym)
             new_points, new_target = out["new_points"], out["new_target"]
         return out["dis"]
+
+    def _run_window_native(frames):
+        """PoseNet phase: the frames of a window (any crop sizes) as multi-bucket passes of at most --window_pixels crop pixels each; returns
+        the frames' distances (device tensor)."""
+        chunks, cur, px = [], [], 0
+        for f in frames:
+            n = int(f[2].shape[-2]) * int(f[2].shape[-1])
+            if cur and px + n > opt.window_pixels:
+                chunks.append(cur); cur, px = [], 0
+            cur.append(f); px += n
+        if cur:
+            chunks.append(cur)
+        dists = []
+        for chunk in chunks:
+            by_size = {}
+            for f in chunk:
+                by_size.setdefault(tuple(f[2].shape[-2:]), []).append(f)
+            order = [f for group in by_size.values() for f in group]
+            imgs = [torch.cat([f[2] for f in group]) for group in by_size.values()]
+            cat = lambda k: torch.cat([f[k] for f in order])
+            sym = [train_utils.host_index(f[5]) in opt.sym_list for f in order]
+            dists.append(native["posenet"].step_posenet_multi(imgs, cat(0), cat(1), cat(5), cat(3), cat(4), sym, opt.w, dropout=True)["dis"])
+        return torch.cat(dists)
 
     def _run_pass(frames):
         points, choose, img = (torch.cat([f[k] for f in frames]) for k in (0, 1, 2))
@@ -397,7 +427,10 @@ def main(argv=None):
                 by_size.setdefault(tuple(f[2].shape[-2:]), []).append(f)
             passes = [group[g0:g0 + max(1, opt.frames_per_pass)] for group in by_size.values() for g0 in range(0, len(group), max(1, opt.frames_per_pass))]
             active = (refine_lanes[0] if refine_lanes else None) if opt.refine_start else lanes
-            if active is not None:
+            if native and not opt.refine_start and opt.passes == "window":
+                if window:
+                    window_dis = window_dis + _run_window_native(window).sum()
+            elif active is not None:
                 for d in active.run([(lambda lane, fs=fs: _run_pass_native(fs, lane)) for fs in passes]):
                     window_dis = window_dis + d.sum()
             else:
