@@ -67,6 +67,9 @@ SIGNATURES = {
     "df_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
     "df_preprocess_objects": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "df_conv2d_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp]),
+    "df_conv2d_nhwc_multi": (_i, [ctypes.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp]),
+    "df_conv2d_wgrad_multi_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc), _i, _vp, _vp, _vp]),
+    "df_conv2d_wgrad_nhwc_multi": (_i, [ctypes.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "df_conv_last_splitk": (_i, []),
     "df_conv3x3_winograd_scratch_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "df_conv3x3_winograd_nhwc": (_i, [ctypes.POINTER(ConvDesc), _vp, ctypes.c_size_t, _vp]),
@@ -82,6 +85,7 @@ SIGNATURES = {
     "df_posenet_train_step": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _f, _i, ctypes.c_uint] + [_vp] * 9 + [_sz, _vp]),
     "df_posenet_train_multi_workspace_bytes": (_sz, [_vp, _i, _vp, _vp, _vp, _i]),
     "df_posenet_train_step_multi": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp] + [_vp] * 5 + [_i, _vp, _f, _i, ctypes.c_uint] + [_vp] * 9 + [_sz, _vp]),
+    "df_trainer_set_splitk": (_i, [_vp, _i]),
     "df_trainer_profile": (_i, [_vp, _i]),
     "df_trainer_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i)]),
     "df_refiner_train_workspace_bytes": (_sz, [_vp, _i, _i]),

@@ -1095,6 +1095,57 @@ extern "C" int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream) {
   return launch_conv(p, to_stream(stream), &t_last_splitk);
 }
 
+// buckets of a multi-bucket convolution / weight-gradient call: pixel rows concatenated in bucket order in both operands
+static int make_segs(const df_conv_desc *d, int nb, const int *B, const int *H, const int *W, std::vector<WgradSeg> &segs, const char *what) {
+  if (!d) return set_error(DF_ERR_ARG, "%s: null descriptor", what);
+  if (nb <= 0 || nb > 4096 || !B || !H || !W) return set_error(DF_ERR_ARG, "%s: need 1..4096 buckets with B / H / W arrays", what);
+  if (d->KH != d->KW) return set_error(DF_ERR_ARG, "%s: square kernels only", what);
+  long in_row = 0, out_row = 0;
+  for (int i = 0; i < nb; ++i) {
+    if (B[i] <= 0 || H[i] <= 0 || W[i] <= 0) return set_error(DF_ERR_ARG, "%s: bucket %d is empty", what, i);
+    const int OH = conv_out(H[i], d->KH, d->stride, d->pad, d->dil), OW = conv_out(W[i], d->KW, d->stride, d->pad, d->dil);
+    if (OH <= 0 || OW <= 0) return set_error(DF_ERR_ARG, "%s: bucket %d: the kernel does not fit the map", what, i);
+    segs.push_back(WgradSeg{B[i], H[i], W[i], OH, OW, in_row, out_row});
+    in_row += (long)B[i] * H[i] * W[i];
+    out_row += (long)B[i] * OH * OW;
+  }
+  return DF_OK;
+}
+
+extern "C" int df_conv2d_nhwc_multi(const df_conv_desc *d, int nb, const int *B, const int *H, const int *W, df_stream_t stream) {
+  std::vector<WgradSeg> segs;
+  int rc = make_segs(d, nb, B, H, W, segs, "conv2d_nhwc_multi");
+  if (rc != DF_OK) return rc;
+  if (d->act == ACT_PRELU && !d->prelu) return set_error(DF_ERR_ARG, "conv2d_nhwc_multi: PReLU needs a slope");
+  ConvParams p;
+  p.in = d->in; p.wgt = d->wgt; p.bias = d->bias; p.res = d->res; p.prelu = d->prelu; p.out = d->out;
+  p.Cin = d->Cin; p.in_ld = d->in_ld; p.in_coff = d->in_coff; p.Cout = d->Cout; p.out_ld = d->out_ld; p.out_coff = d->out_coff;
+  p.res_ld = d->res_ld; p.res_coff = d->res_coff;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.act = d->act;
+  return launch_conv_multi(p, nb, segs.data(), to_stream(stream));
+}
+
+extern "C" size_t df_conv2d_wgrad_multi_workspace_bytes(const df_conv_desc *d, int nb, const int *B, const int *H, const int *W) {
+  std::vector<WgradSeg> segs;
+  if (make_segs(d, nb, B, H, W, segs, "conv2d_wgrad_multi_workspace_bytes") != DF_OK) return 0;
+  ConvParams p;
+  p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
+  return wgrad_multi_workspace_bytes(p, nb, segs.data());
+}
+
+extern "C" int df_conv2d_wgrad_nhwc_multi(const df_conv_desc *d, int nb, const int *B, const int *H, const int *W, const float *dy, float *dw, float *db,
+                                          void *ws, size_t ws_bytes, df_stream_t stream) {
+  std::vector<WgradSeg> segs;
+  int rc = make_segs(d, nb, B, H, W, segs, "conv2d_wgrad_multi");
+  if (rc != DF_OK) return rc;
+  if (!dy || !dw || !d->in) return set_error(DF_ERR_ARG, "conv2d_wgrad_multi: null pointer");
+  ConvParams p;
+  p.in = d->in; p.out = const_cast<float *>(dy);
+  p.Cin = d->Cin; p.in_ld = d->in_ld; p.in_coff = d->in_coff; p.Cout = d->Cout; p.out_ld = d->out_ld; p.out_coff = d->out_coff;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+  return launch_wgrad_multi(p, nb, segs.data(), dw, db, ws, ws_bytes, to_stream(stream));
+}
+
 // 3x3 stride-1 pad=dil convolution through the Winograd F(2x2,3x3) / F(4x4,3x3) domain (wino.hip): weight transform, input
 // transform, 16 / 36 batched GEMMs, output transform (+ bias, residual, ReLU).  scratch holds U | V | M.
 static int wino_desc_ok(const df_conv_desc *d, const char *what) {

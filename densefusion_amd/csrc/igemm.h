@@ -57,6 +57,16 @@ double conv_flops(const ConvParams &p);
 double conv_bytes(const ConvParams &p);
 int launch_conv(const ConvParams &p, hipStream_t st, int *splitk_used = nullptr);     // splitk_used: the K ranges the launch was cut into
 
+// One crop-size bucket of a multi-bucket launch: B maps of H x W (outputs OH x OW) whose input / output pixel rows start at
+// in_row0 / out_row0 of the concatenated buffers
+struct WgradSeg { int B, H, W, OH, OW; long in_row0, out_row0; };
+// The same convolution over SEVERAL crop-size buckets whose pixel rows are concatenated in p.in / p.out / p.res (p.B / H / W / OH / OW are
+// ignored): ONE launch of the product kernel (a workgroup's tile lies inside one bucket), CONV_MAX_BUCKETS buckets per launch.  Same
+// sums in the same order per output element as per-bucket launch_conv calls without split-K.  Shapes the multi-bucket instantiations
+// do not cover (input dilation, grouped / column-sum launches) fall back to one launch per bucket.
+constexpr int CONV_MAX_BUCKETS = 16;
+int launch_conv_multi(const ConvParams &p, int nseg, const WgradSeg *segs, hipStream_t st);
+
 // dW[n][(ky,kx,c)] += sum_m dY[m][n] * A[m][(ky,kx,c)]  (A = the im2col view of x of the forward conv `p`; p.out = dY)
 // dw / db (optional: column sums of dY) are overwritten.  The pixel range is split over workgroups; the partial tiles go to `ws`
 // (wgrad_workspace_bytes) and are added in a fixed order: bit-reproducible, no atomics.
@@ -70,7 +80,6 @@ int launch_wgrad(const ConvParams &p, float *dw, float *db, void *ws, size_t ws_
 // are ignored; everything else (channels, strides, kernel geometry) comes from p.  Up to WGRAD_MAX_SEGS buckets per launch (more:
 // several launches, the later ones accumulating).
 constexpr int WGRAD_MAX_SEGS = 32;
-struct WgradSeg { int B, H, W, OH, OW; long in_row0, out_row0; };
 size_t wgrad_multi_workspace_bytes(const ConvParams &p, int nseg, const WgradSeg *segs);
 int launch_wgrad_multi(const ConvParams &p, int nseg, const WgradSeg *segs, float *dw, float *db, void *ws, size_t ws_bytes, hipStream_t st,
                        int accumulate = 0);

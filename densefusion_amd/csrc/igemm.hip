@@ -555,8 +555,21 @@ __global__ __launch_bounds__(256) void igemm_f32_v2_kernel(const ConvParams p) {
 // LOADER: 0 general (any geometry, K tail), 1 plain GEMM, 2 multi-tap with Cin a power of two >= BKT (a k tile lies inside one tap)
 // COLSUM: the launches with a fused column sum (p.colsum; p.out may be null) -- their own instantiation, so that the others carry no
 // per-pass tests for it.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int OCC, int LOADER, bool COLSUM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void igemm_f32_v4_kernel(const ConvParams p) {
+// MULTI: several crop-size buckets in ONE launch (the training step's direct k x k convolutions over a window of mixed crop sizes).
+// The buckets' pixel rows are concatenated in p.in / p.out / p.res; the linear workgroup index selects a bucket (`tab`, by value in the
+// kernel arguments), whose map size, tile counts, division magics and row offsets replace the launch-wide ones; everything after that
+// is the single-geometry kernel.  Tiles never straddle buckets (a bucket's rows are tiled on their own).
+struct ConvBuckets {
+  int n;
+  int tile0[CONV_MAX_BUCKETS + 1];      // first linear workgroup of bucket g
+  int B[CONV_MAX_BUCKETS], H[CONV_MAX_BUCKETS], W[CONV_MAX_BUCKETS], OH[CONV_MAX_BUCKETS], OW[CONV_MAX_BUCKETS];
+  int tiles_m[CONV_MAX_BUCKETS], tile_full[CONV_MAX_BUCKETS], full_sh[CONV_MAX_BUCKETS], ohw_sh[CONV_MAX_BUCKETS], ow_sh[CONV_MAX_BUCKETS];
+  unsigned full_magic[CONV_MAX_BUCKETS], ohw_magic[CONV_MAX_BUCKETS], ow_magic[CONV_MAX_BUCKETS];
+  long in_row0[CONV_MAX_BUCKETS], out_row0[CONV_MAX_BUCKETS];
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int OCC, int LOADER, bool COLSUM, bool MULTI>
+__device__ __forceinline__ void igemm_f32_v4_body(const ConvParams &pk, const ConvBuckets *tab) {
   constexpr bool PURE = LOADER == 1, TAPU = LOADER == 2;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -576,15 +589,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  const int M = p.B * p.OH * p.OW;
-  const int K = p.KH * p.KW * p.Cin;
-  const int tiles_n = (p.Cout + BN - 1) / BN;
   int wgid;
   {
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
+  ConvParams pl;
+  if constexpr (MULTI) {
+    pl = pk;
+    int g = 0;
+    while (g + 1 < tab->n && wgid >= tab->tile0[g + 1]) ++g;      // workgroup-uniform: scalar loads of the table
+    wgid -= tab->tile0[g];
+    pl.B = tab->B[g]; pl.H = tab->H[g]; pl.W = tab->W[g]; pl.OH = tab->OH[g]; pl.OW = tab->OW[g];
+    pl.tiles_m = tab->tiles_m[g]; pl.tile_full = tab->tile_full[g];
+    pl.full_magic = tab->full_magic[g]; pl.full_sh = tab->full_sh[g];
+    pl.ohw_magic = tab->ohw_magic[g]; pl.ohw_sh = tab->ohw_sh[g]; pl.ow_magic = tab->ow_magic[g]; pl.ow_sh = tab->ow_sh[g];
+    pl.in = pk.in + tab->in_row0[g] * pk.in_ld;
+    pl.out = pk.out + tab->out_row0[g] * pk.out_ld;
+    if (pk.res) pl.res = pk.res + tab->out_row0[g] * pk.res_ld;
+  }
+  const ConvParams &p = MULTI ? pl : pk;
+  const int M = p.B * p.OH * p.OW;
+  const int K = p.KH * p.KW * p.Cin;
+  const int tiles_n = (p.Cout + BN - 1) / BN;
   // column-tile groups: when the weight operand is too big for an XCD's L2 (4 MB), the tiles are walked group by group
   // (p.ngroup column tiles, all row blocks, next group ...) so that the group's weight slice stays L2-resident while the
   // activation rows stream through once per group instead of every column tile missing on both operands
@@ -913,6 +941,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   DF_TRACE_WAVE_END(wave);
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int OCC, int LOADER, bool COLSUM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void igemm_f32_v4_kernel(const ConvParams p) {
+  igemm_f32_v4_body<BM, BN, WAVES_M, WAVES_N, BKT, OCC, LOADER, COLSUM, false>(p, nullptr);
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int OCC, int LOADER>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void igemm_f32_v4_multi_kernel(const ConvParams p, const ConvBuckets tab) {
+  igemm_f32_v4_body<BM, BN, WAVES_M, WAVES_N, BKT, OCC, LOADER, false, true>(p, &tab);
+}
+
 // split-K reduce: out = act(sum_s partial[s] + bias + res), partials added in the order s = 0, 1, ... (deterministic).  thread = 4 channels
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int S, long M, int Cout, float *__restrict__ out,
                                                             int out_ld, int out_coff, const float *__restrict__ bias,
@@ -1049,8 +1086,9 @@ struct WgTab {
   long in_row0[WGRAD_MAX_SEGS], out_row0[WGRAD_MAX_SEGS];
 };
 
-template <int TN_>
-__global__ __launch_bounds__(256) void wgrad_f32_v2_kernel(const ConvParams p, float *__restrict__ part, int m_chunk, const WgTab tab) {
+template <int TN_, int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void wgrad_f32_v2_kernel(const ConvParams p, float *__restrict__ part, int m_chunk, int split,
+                                                                                                          const WgTab tab) {
   static_assert(TN_ == 64 || TN_ == 128, "n side of the tile");
   constexpr int TK_ = 128, RM = 32;
   constexpr int LDY = TN_ + 4, LDA = TK_ + 4;        // row strides: the second pixel of a step lands 4 banks further (2-way at worst)
@@ -1061,15 +1099,32 @@ __global__ __launch_bounds__(256) void wgrad_f32_v2_kernel(const ConvParams p, f
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
+  // XCD-aware order of the (tile, pixel chunk) pairs (1-D grid; the hardware deals workgroups to the 8 XCDs round-robin): an XCD gets a
+  // contiguous run of the sequence below, i.e. output tiles that share their dY column block and -- taps fastest -- the channel block of
+  // x they contract with, for all pixel chunks: its L2 (4 MB) then serves the nine taps' re-reads of the same activation rows and the
+  // column tiles' re-reads of dY.  (With tiles dealt round-robin every XCD touched every k block: ~6x the traffic behind the L2.)
+  int wgid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int K = p.KH * p.KW * p.Cin;
+  const int tiles_k = (K + TK_ - 1) / TK_;
+  const int tile_o = wgid / split, zz = wgid - tile_o * split;
+  int n_blk = tile_o / tiles_k, kt = tile_o - n_blk * tiles_k;
+  if (p.KH * p.KW > 1 && p.Cin % TK_ == 0) {      // k tile = (tap, channel block): walk the taps of a channel block first
+    const int T = p.KH * p.KW, cb = kt / T, tap = kt - cb * T;
+    kt = tap * (p.Cin / TK_) + cb;
+  }
   int sg = 0;
-  while (sg + 1 < tab.n && (int)blockIdx.z >= tab.z0[sg + 1]) ++sg;      // (workgroup-uniform: scalar loads of the table)
-  const int M = tab.M[sg], K = p.KH * p.KW * p.Cin;
+  while (sg + 1 < tab.n && zz >= tab.z0[sg + 1]) ++sg;      // (workgroup-uniform: scalar loads of the table)
+  const int M = tab.M[sg];
   const int sH = tab.H[sg], sW = tab.W[sg], sOW = tab.OW[sg];
   const unsigned ohw_magic = tab.ohw_magic[sg], ow_magic = tab.ow_magic[sg];
   const int ohw_sh = tab.ohw_sh[sg], ow_sh = tab.ow_sh[sg];
-  const int tiles_k = (K + TK_ - 1) / TK_;
-  const int n0 = (blockIdx.x / tiles_k) * TN_, k0 = (blockIdx.x % tiles_k) * TK_;
-  const int m_begin = ((int)blockIdx.z - tab.z0[sg]) * m_chunk, m_end = min(M, m_begin + m_chunk);
+  const int n0 = n_blk * TN_, k0 = kt * TK_;
+  const int m_begin = (zz - tab.z0[sg]) * m_chunk, m_end = min(M, m_begin + m_chunk);
   const int nt = (m_end - m_begin + RM - 1) / RM;
 
   const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in) + tab.in_row0[sg] * p.in_ld, 0,
@@ -1158,7 +1213,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_v2_kernel(const ConvParams p, f
     }
     __syncthreads();
   }
-  float *dst = part + (size_t)blockIdx.z * p.Cout * K;
+  float *dst = part + (size_t)zz * p.Cout * K;
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -1408,6 +1463,87 @@ int launch_conv(const ConvParams &p, hipStream_t st, int *splitk_used) {
   return check_launch("igemm");
 }
 
+// Direct k x k convolution over several crop-size buckets in one launch (igemm_f32_v4_multi_kernel); see igemm.h.
+int launch_conv_multi(const ConvParams &p, int nseg, const WgradSeg *segs, hipStream_t st) {
+  if (!p.in || !p.wgt || !p.out || nseg <= 0 || !segs) return set_error(DF_ERR_ARG, "conv_multi: null pointer");
+  const int taps = p.KH * p.KW;
+  // what the multi-bucket instantiations cover: the product kernel's general and tap-uniform loaders, no grouping, no fused sums
+  const bool ok = p.up == 1 && p.zcount == 1 && !p.colsum && p.rows_per_group == 0 && p.bias_group_ld == 0 && p.Cin % 4 == 0 && p.in_ld % 4 == 0 &&
+                  p.in_coff % 4 == 0 && p.Cout % 4 == 0 && p.out_ld % 4 == 0 && p.out_coff % 4 == 0 && (!p.res || (p.res_ld % 4 == 0 && p.res_coff % 4 == 0)) &&
+                  (taps == 1 || !(p.Cin & (p.Cin - 1))) && p.out_ld < (1 << 21) && p.res_ld < (1 << 21);
+  if (!ok || nseg == 1) {          // anything else: one launch per bucket
+    for (int g = 0; g < nseg; ++g) {
+      ConvParams q = p;
+      q.B = segs[g].B; q.H = segs[g].H; q.W = segs[g].W; q.OH = segs[g].OH; q.OW = segs[g].OW;
+      q.in = p.in + segs[g].in_row0 * p.in_ld; q.out = p.out + segs[g].out_row0 * p.out_ld;
+      if (p.res) q.res = p.res + segs[g].out_row0 * p.res_ld;
+      const int rc = launch_conv(q, st);
+      if (rc != DF_OK) return rc;
+    }
+    return DF_OK;
+  }
+  for (int g0 = 0; g0 < nseg; g0 += CONV_MAX_BUCKETS) {
+    const int n = std::min(CONV_MAX_BUCKETS, nseg - g0);
+    long Mtot = 0;
+    bool small_ok = true;
+    for (int g = g0; g < g0 + n; ++g) {
+      const WgradSeg &sg = segs[g];
+      if (sg.B <= 0 || sg.H <= 0 || sg.W <= 0 || sg.OH <= 0 || sg.OW <= 0) return set_error(DF_ERR_ARG, "conv_multi: empty bucket");
+      Mtot += (long)sg.B * sg.OH * sg.OW;
+      const size_t in_bytes = (size_t)sg.B * sg.H * sg.W * p.in_ld * sizeof(float);
+      const size_t shifted = ((size_t)sg.B * sg.H * sg.W + (size_t)p.pad * sg.W + p.pad) * p.in_ld * sizeof(float);
+      small_ok = small_ok && in_bytes < (1ull << 32) && shifted < (1ull << 31) && sg.H + p.pad < 32768 && sg.W + p.pad < 32768 &&
+                 (size_t)sg.B * sg.OH * sg.OW * p.out_ld < (1ull << 40);
+    }
+    if (!small_ok) return set_error(DF_ERR_ARG, "conv_multi: a bucket is too large for the multi-bucket kernel");
+    ConvParams pt = p;             // tile choice on the whole launch's rows
+    pt.B = (int)std::min<long>(Mtot, 1L << 30); pt.OH = pt.OW = 1;
+    const TileCfg c = pick_cfg(pt);
+    ConvParams pl = p;
+    {
+      const size_t slice = (size_t)c.bn * taps * p.Cin * sizeof(float);
+      const long tn = (p.Cout + c.bn - 1) / c.bn;
+      const long budget = 3L << 20;
+      pl.ngroup = (size_t)tn * slice > (size_t)budget ? (int)std::max<long>(1, budget / (long)slice) : 0;
+    }
+    const int tiles_n = (p.Cout + c.bn - 1) / c.bn;
+    pl.tile_gn = pl.ngroup > 0 && pl.ngroup < tiles_n ? pl.ngroup : tiles_n;
+    const int last = tiles_n % pl.tile_gn;
+    make_fdiv(pl.tile_gn, pl.gn_magic, pl.gn_sh);
+    make_fdiv(last ? last : pl.tile_gn, pl.gl_magic, pl.gl_sh);
+    make_fdiv(1, pl.rpg_magic, pl.rpg_sh);
+    pl.splitk = 1;
+    ConvBuckets tab;
+    tab.n = n;
+    tab.tile0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+      const WgradSeg &sg = segs[g0 + i];
+      const long M = (long)sg.B * sg.OH * sg.OW;
+      tab.B[i] = sg.B; tab.H[i] = sg.H; tab.W[i] = sg.W; tab.OH[i] = sg.OH; tab.OW[i] = sg.OW;
+      tab.tiles_m[i] = (int)((M + c.bm - 1) / c.bm);
+      tab.tile_full[i] = tab.tiles_m[i] * pl.tile_gn;
+      make_fdiv(tab.tile_full[i], tab.full_magic[i], tab.full_sh[i]);
+      make_fdiv((long)sg.OH * sg.OW, tab.ohw_magic[i], tab.ohw_sh[i]);
+      make_fdiv(sg.OW, tab.ow_magic[i], tab.ow_sh[i]);
+      tab.in_row0[i] = sg.in_row0; tab.out_row0[i] = sg.out_row0;
+      tab.tile0[i + 1] = tab.tile0[i] + tab.tiles_m[i] * tiles_n;
+    }
+    const dim3 grid((unsigned)tab.tile0[n], 1, 1);
+    constexpr size_t ROW = 36 * sizeof(float);
+    const int loader = taps > 1 && taps <= 32 && p.Cin >= 32 ? 2 : 0;
+    auto launch = [&](auto bm, auto bn, auto occ, size_t rows) {
+      constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value, OCC_ = decltype(occ)::value;
+      if (loader == 2) hipLaunchKernelGGL((igemm_f32_v4_multi_kernel<BM_, BN_, 2, 2, 32, OCC_, 2>), grid, dim3(256), rows * ROW, st, pl, tab);
+      else hipLaunchKernelGGL((igemm_f32_v4_multi_kernel<BM_, BN_, 2, 2, 32, OCC_, 0>), grid, dim3(256), rows * ROW, st, pl, tab);
+    };
+    using std::integral_constant;
+    if (c.bm == 128 && c.bn == 128) launch(integral_constant<int, 128>{}, integral_constant<int, 128>{}, integral_constant<int, 4>{}, 256);
+    else if (c.bm == 128) launch(integral_constant<int, 128>{}, integral_constant<int, 64>{}, integral_constant<int, 5>{}, 192);
+    else launch(integral_constant<int, 64>{}, integral_constant<int, 64>{}, integral_constant<int, 6>{}, 128);
+  }
+  return check_launch("igemm (multi-bucket)");
+}
+
 namespace {
 struct WgradPlan { bool big; int tiles, split, chunk, nblk; size_t part_floats, bias_floats; };
 
@@ -1421,7 +1557,8 @@ WgradPlan wgrad_plan(const ConvParams &p, int nseg, const WgradSeg *segs) {
   const int tn = w.big && p.Cout >= 128 ? 128 : 64, tk = w.big ? 128 : 64;
   w.tiles = ((p.Cout + tn - 1) / tn) * ((K + tk - 1) / tk);
   // split the pixel range so that one round of workgroups (4 per CU: 1024) is in flight, each with at least 256 pixels
-  long split = 1024 / w.tiles;
+  static const long slots = getenv("DF_WGRAD_SLOTS") ? atol(getenv("DF_WGRAD_SLOTS")) : 1024;      // TEMPORARY A/B switch
+  long split = slots / w.tiles;
   const long max_split = (M + 255) / 256;
   if (split > max_split) split = max_split;
   if (split > 256) split = 256;          // (the partial slices are re-read by the reduction)
@@ -1482,16 +1619,29 @@ static int launch_wgrad_segs(ConvParams p, int nseg, const WgradSeg *segs, float
       tab.in_row0[g] = sg.in_row0; tab.out_row0[g] = sg.out_row0;
       tab.z0[g + 1] = tab.z0[g] + (int)((Mg + w.chunk - 1) / w.chunk);
     }
-    static bool attr_done[64] = {};
-    int dev = 0;
-    hipGetDevice(&dev);
     constexpr size_t lds128 = (size_t)32 * (132 + 132) * 4, lds64 = (size_t)32 * (68 + 132) * 4;
-    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-      hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_f32_v2_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
-      attr_done[dev] = true;
+    static const int occ = getenv("DF_WGRAD_OCC") ? atoi(getenv("DF_WGRAD_OCC")) : 2;      // TEMPORARY A/B switch
+    auto go = [&](auto tn, auto oc, size_t lds) {
+      constexpr int TN = decltype(tn)::value, OC = decltype(oc)::value;
+      static bool attr_done[64] = {};
+      int dev = 0;
+      hipGetDevice(&dev);
+      if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_f32_v2_kernel<TN, OC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done[dev] = true;
+      }
+      hipLaunchKernelGGL((wgrad_f32_v2_kernel<TN, OC>), dim3((unsigned)(w.tiles * w.split)), dim3(256), lds, st, p, part, w.chunk, w.split, tab);
+    };
+    using std::integral_constant;
+    if (p.Cout >= 128) {
+      if (occ == 4) go(integral_constant<int, 128>{}, integral_constant<int, 4>{}, lds128);
+      else if (occ == 3) go(integral_constant<int, 128>{}, integral_constant<int, 3>{}, lds128);
+      else go(integral_constant<int, 128>{}, integral_constant<int, 2>{}, lds128);
+    } else {
+      if (occ == 4) go(integral_constant<int, 64>{}, integral_constant<int, 4>{}, lds64);
+      else if (occ == 3) go(integral_constant<int, 64>{}, integral_constant<int, 3>{}, lds64);
+      else go(integral_constant<int, 64>{}, integral_constant<int, 2>{}, lds64);
     }
-    if (p.Cout >= 128) hipLaunchKernelGGL(wgrad_f32_v2_kernel<128>, dim3(w.tiles, 1, w.split), dim3(256), lds128, st, p, part, w.chunk, tab);
-    else hipLaunchKernelGGL(wgrad_f32_v2_kernel<64>, dim3(w.tiles, 1, w.split), dim3(256), lds64, st, p, part, w.chunk, tab);
   } else {
     // the small-shape kernel decodes one geometry: one launch per bucket into consecutive partial slices
     int z = 0;

@@ -40,7 +40,7 @@ __device__ inline int block_excl_scan(int v, int *s_buf, int &total) {
 struct ObjDesc {   // one object: frame index and snapped bounding box (host side: get_bbox, eval_ycb.py:54-90)
   int frame, itemid, rmin, rmax, cmin, cmax;
   unsigned seed;
-  int pad;
+  int given;         // != 0: this object's row of `choose` was filled in by the caller (chosen indices as an INPUT): step 2 is skipped
 };
 
 // grid = B objects, block = 1024.  rgb [F][IH][IW][3] u8, depth [F][IH][IW] u16, label [F][IH][IW] i32.
@@ -76,7 +76,10 @@ __global__ __launch_bounds__(PB) void preprocess_kernel(const unsigned char *__r
   __syncthreads();
   // 2. choose
   int64_t *ch = choose + (size_t)b * N;
-  if (total == 0) {
+  if (o.given) {
+    // the caller's indices (e.g. the subset the reference's np.random.shuffle drew): clamped into the crop, otherwise taken as they are
+    for (int j = tid; j < N; j += PB) { const int64_t v = ch[j]; ch[j] = v < 0 ? 0 : (v >= HW ? HW - 1 : v); }
+  } else if (total == 0) {
     for (int j = tid; j < N; j += PB) ch[j] = 0;     // detector lost the object; the caller checks count
   } else if (total <= N) {
     for (int j = tid; j < N; j += PB) ch[j] = nz[j % total];        // np.pad(..., 'wrap')

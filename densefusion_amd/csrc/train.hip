@@ -15,6 +15,7 @@
 //
 // Reference lines mirrored: lib/extractors.py:29-43,114-124; lib/pspnet.py:20-24,27-37,64-77; lib/network.py:53-68,95-132,151-206;
 // lib/loss.py:13-70; lib/loss_refiner.py:12-62.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -180,15 +181,15 @@ __global__ __launch_bounds__(TB) void bilinear_fwd_kernel(const float *__restric
     *reinterpret_cast<f32x4 *>(y + pix * y_ld + c) = o;
   }
 }
-// adjoint as a gather: dx[b][q] = sum over the destination pixels that read q of weight * dy.  Workgroup = 32 channel vectors x 8 row
-// lanes: lane l takes the candidate destination rows lo + l, lo + l + 8, ... (columns ascending inside a row), the 8 partial sums
-// meet in LDS and are added in lane order -- a fixed order, and 8 load chains instead of one (the 1 x 1 pyramid stage gathers the
-// whole map into one pixel)
+// adjoint as a gather: dx[b][q] = sum over the destination pixels that read q of weight * dy.  Workgroup = 8 channel vectors x 32
+// pixel lanes: lane l takes the candidate destination pixels l, l + 32, ... of q's (row range) x (column range) window, the 32 partial
+// sums meet in LDS and are added in lane order -- a fixed order, and 32 load chains per output instead of one (the 1 x 1 pyramid stage
+// gathers the whole map into one pixel: with 8 row lanes it was the longest glue kernel of a mixed-size training window)
 __global__ __launch_bounds__(TB) void bilinear_bwd_kernel(const float *__restrict__ dy, int dy_ld, float *__restrict__ dx, int B, int H, int W, int C4,
                                                           int OH, int OW, int align) {
-  __shared__ f32x4 s_p[8][32];
-  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int cgroups = (C4 + 31) / 32;
+  __shared__ f32x4 s_p[32][8];
+  const int col = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int cgroups = (C4 + 7) / 8;
   for (long job = blockIdx.x; job < (long)B * H * W * cgroups; job += gridDim.x) {
     const int cg = (int)(job % cgroups);
     long r = job / cgroups;
@@ -196,34 +197,32 @@ __global__ __launch_bounds__(TB) void bilinear_bwd_kernel(const float *__restric
     const int qx = (int)(r % W); r /= W;
     const int qy = (int)(r % H);
     const int b = (int)(r / H);
-    const int c4 = cg * 32 + col;
+    const int c4 = cg * 8 + col;
     int ylo, yhi, xlo, xhi;
     bil_cands(qy, H, OH, align, ylo, yhi);
     bil_cands(qx, W, OW, align, xlo, xhi);
+    const int nx = xhi - xlo + 1, total = (yhi - ylo + 1) * nx;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (c4 < C4)
-      for (int oy = ylo + rl; oy <= yhi; oy += 8) {
-        int y0, y1;
-        float wy0, wy1;
+      for (int idx = pl; idx < total; idx += 32) {
+        const int oy = ylo + idx / nx, ox = xlo + idx % nx;
+        int y0, y1, x0, x1;
+        float wy0, wy1, wx0, wx1;
         bil_src(oy, H, OH, align, y0, y1, wy0, wy1);
         if (y0 != qy && y1 != qy) continue;
+        bil_src(ox, W, OW, align, x0, x1, wx0, wx1);
+        if (x0 != qx && x1 != qx) continue;
         const float wy = (y0 == qy ? wy0 : 0.f) + (y1 == qy ? wy1 : 0.f);
-        for (int ox = xlo; ox <= xhi; ++ox) {
-          int x0, x1;
-          float wx0, wx1;
-          bil_src(ox, W, OW, align, x0, x1, wx0, wx1);
-          if (x0 != qx && x1 != qx) continue;
-          const float wx = (x0 == qx ? wx0 : 0.f) + (x1 == qx ? wx1 : 0.f);
-          const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + ((long)(b * OH + oy) * OW + ox) * dy_ld + c4 * 4);
+        const float wx = (x0 == qx ? wx0 : 0.f) + (x1 == qx ? wx1 : 0.f);
+        const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + ((long)(b * OH + oy) * OW + ox) * dy_ld + c4 * 4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] += (wy * wx) * g[e];
-        }
+        for (int e = 0; e < 4; ++e) acc[e] += (wy * wx) * g[e];
       }
-    s_p[rl][col] = acc;
+    s_p[pl][col] = acc;
     __syncthreads();
-    if (rl == 0 && c4 < C4) {
-#pragma unroll
-      for (int l = 1; l < 8; ++l)
+    if (pl == 0 && c4 < C4) {
+#pragma unroll 4
+      for (int l = 1; l < 32; ++l)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] += s_p[l][col][e];
       reinterpret_cast<f32x4 *>(dx)[pix * C4 + c4] = acc;
@@ -684,6 +683,7 @@ struct Trainer {
   size_t wino_floats = 0;
   FlipSeg *flip_tab = nullptr;     // device copy of `flips` for the one-launch flip
   long flip_total = 0;
+  bool splitk = true;             // df_trainer_set_splitk
   // df_trainer_profile: HIP event pairs around every MFMA launch of a step, executed FLOPs per kind (0 fwd, 1 dgrad, 2 wgrad)
   bool profiling = false;
   std::vector<hipEvent_t> ev;
@@ -933,6 +933,15 @@ struct Step {
     fail(launch_conv(p, st));
     prof_end(kind, conv_flops(p));
   }
+  // the same convolution over several buckets: one launch (launch_conv_multi)
+  void gemm_multi(int kind, const ConvParams &p, const std::vector<WgradSeg> &segs) {
+    if (!live() || segs.empty()) return;
+    double fl = 0;
+    for (const WgradSeg &g : segs) fl += 2.0 * g.B * g.OH * g.OW * (double)p.Cout * p.KH * p.KW * p.Cin;
+    prof_begin();
+    fail(launch_conv_multi(p, (int)segs.size(), segs.data(), st));
+    prof_end(kind, fl);
+  }
   size_t slot(const std::string &name) {
     auto it = t->slot.find(name);
     if (it == t->slot.end()) {
@@ -1077,14 +1086,24 @@ Act *conv(Step &s, Act *x, int cin, const ConvW &cw, int cout, int k, int stride
     plan->push_back(p);
     s.gemm(GK_FWD, p);
   } else {
+    std::vector<WgradSeg> direct;
+    int first_direct = -1;
     for (int i = 0; i < nb; ++i) {
       ConvParams p = bucket_params(x, i, cin, wp, bp, y, k, stride, pad, dil, act);
       if (res) { p.res = res->v.d + lo->off[i] * res->v.ld; p.res_ld = res->v.ld; }
       p.prelu = slope;
       p.splitk_ws = s.splitk; p.splitk_ws_bytes = s.splitk_bytes;
       plan->push_back(p);
-      if (wino_ok && wino_route(li->H[i], li->W[i], dil, cin, cout) == 4) f4->push_back(i);
-      else s.gemm(GK_FWD, p);
+      if (wino_ok && wino_route(li->H[i], li->W[i], dil, cin, cout) == 4) { f4->push_back(i); continue; }
+      if (first_direct < 0) first_direct = i;
+      direct.push_back(WgradSeg{li->B[i], li->H[i], li->W[i], lo->H[i], lo->W[i], li->off[i], lo->off[i]});
+    }
+    if (direct.size() == 1) s.gemm(GK_FWD, (*plan)[first_direct]);
+    else if (!direct.empty()) {      // the direct kernel over all of them in one launch (a workgroup's tile lies inside one bucket)
+      ConvParams p = (*plan)[0];
+      p.in = x->v.d; p.out = y->v.d;
+      if (res) p.res = res->v.d;
+      s.gemm_multi(GK_FWD, p, direct);
     }
   }
   // transform-domain pass over the buckets of `f4` (stride 1: input and output levels have the same rows)
@@ -1131,10 +1150,25 @@ Act *conv(Step &s, Act *x, int cin, const ConvW &cw, int cout, int k, int stride
       const bool acc = s.grad_of(x);
       if (flat) dgrad(s, (*plan)[0], y->g, x->g, s.pf(cw.name, cw.woff), acc);
       else {
+        std::vector<int> direct;
         for (int i = 0; i < nb; ++i) {
           bool on_f4 = false;
           for (int j : *f4) on_f4 |= j == i;
-          if (!on_f4) dgrad(s, (*plan)[i], rows_view(y->g, lo->off[i]), rows_view(x->g, li->off[i]), s.pf(cw.name, cw.woff), acc);
+          if (!on_f4) direct.push_back(i);
+        }
+        if (direct.size() == 1 || stride != 1)        // (a strided convolution's data gradient reads a dilated input: the un-pipelined kernel, per bucket)
+          for (int i : direct) dgrad(s, (*plan)[i], rows_view(y->g, lo->off[i]), rows_view(x->g, li->off[i]), s.pf(cw.name, cw.woff), acc);
+        else if (!direct.empty()) {
+          const ConvParams &f = (*plan)[0];
+          ConvParams q;
+          q.in = y->g.d; q.Cin = f.Cout; q.in_ld = y->g.ld;
+          q.wgt = s.pf(cw.name, cw.woff);
+          q.out = x->g.d; q.Cout = f.Cin; q.out_ld = x->g.ld;
+          q.KH = f.KH; q.KW = f.KW; q.stride = 1; q.dil = f.dil; q.pad = f.dil * (f.KH - 1) - f.pad;
+          if (acc) { q.res = x->g.d; q.res_ld = x->g.ld; }
+          std::vector<WgradSeg> segs;
+          for (int i : direct) segs.push_back(WgradSeg{lo->B[i], lo->H[i], lo->W[i], li->H[i], li->W[i], lo->off[i], li->off[i]});
+          s.gemm_multi(GK_DGRAD, q, segs);
         }
         wino_pass(s, y->g, cout, s.dry || !wino_ok ? nullptr : s.t->wino_buf + wit->second.bwd, x->g, cin, acc ? x->g.d : nullptr, x->g.ld, ACT_NONE, GK_DGRAD);
       }
@@ -1279,6 +1313,7 @@ void posenet_step(Step &s, const PoseNetIO &io) {
   const int nb = io.nb, N = t.N, Npad = round_up(N, 128), rows = B * Npad;
   s.splitk_bytes = (size_t)32 << 20;
   s.splitk = static_cast<float *>(s.bytes(s.splitk_bytes));
+  if (!t.splitk) { s.splitk = nullptr; s.splitk_bytes = 0; }      // (allocated either way: the workspace size does not depend on the switch)
   Step *sp = &s;
 
   // ---- colour branch (lib/extractors.py:114-124, lib/pspnet.py:64-77) ----
@@ -1353,7 +1388,7 @@ void posenet_step(Step &s, const PoseNetIO &io) {
       s.grad_of(z);
       if (s.live())
         for (int i = 0; i < nb; ++i)
-          hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)((long)l8->B[i] * sz * sz * 4)), dim3(TB), 0, s.st, cat->g.d + l8->off[i] * cat->g.ld + 512 * si,
+          hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)((long)l8->B[i] * sz * sz * 16)), dim3(TB), 0, s.st, cat->g.d + l8->off[i] * cat->g.ld + 512 * si,
                              cat->g.ld, z->g.d + (size_t)l8->b0[i] * sz * sz * 512, l8->B[i], sz, sz, 128, l8->H[i], l8->W[i], 0);
     });
   }
@@ -1576,6 +1611,7 @@ void refiner_step(Step &s, const RefinerIO &io) {
   Step *sp = &s;
   s.splitk_bytes = (size_t)8 << 20;
   s.splitk = static_cast<float *>(s.bytes(s.splitk_bytes));
+  if (!t.splitk) { s.splitk = nullptr; s.splitk_bytes = 0; }
   Act *emb_pm = s.act((long)rows, 32);
   if (s.live()) {
     hipMemsetAsync(emb_pm->v.d, 0, (size_t)rows * 32 * sizeof(float), s.st);
@@ -1839,6 +1875,15 @@ extern "C" int df_posenet_train_step(df_trainer *h, const float *flat_param, flo
   return df_posenet_train_step_multi(h, flat_param, flat_grad, param_version, 1, &B, &H, &W, &img, cloud, choose, obj, target, model_points, M,
                                      symmetric_host, w, dropout, seed, loss_out, dis_out, new_points, new_target, out_r, out_t, out_c, emb, ws, ws_bytes,
                                      stream);
+}
+
+// Split-K of the small-grid forward / data-gradient launches (on by default: +4-8 % on one-frame passes).  Off: every output element is
+// summed in ONE order whatever the grid, so the gradient of a frame no longer depends on which other frames share its pass (up to the
+// weight gradients' own pixel order): what the equality tests of the multi-bucket pass switch off.
+extern "C" int df_trainer_set_splitk(df_trainer *h, int enable) {
+  if (!h) return set_error(DF_ERR_ARG, "trainer_set_splitk: null handle");
+  as_trainer(h)->splitk = enable != 0;
+  return DF_OK;
 }
 
 // Profile of the MFMA launches of the steps run on this handle since df_trainer_profile(h, 1): HIP events bracket every forward /

@@ -215,8 +215,9 @@ class PoseDataset:
                 torch.tensor([rmin, rmax, cmin, cmax, count, self.objlist.index(obj)], dtype=torch.int64), target, model_points,
                 torch.from_numpy((add_t if self.add_noise else np.zeros(3)).astype(np.float32)))
 
-    def device_item(self, index, host):
-        """Device half: uploads + one preparation launch on the current stream, no read-back.  Same 6-tuple as ``__getitem__``."""
+    def device_item(self, index, host, choose=None):
+        """Device half: uploads + one preparation launch on the current stream, no read-back.  Same 6-tuple as ``__getitem__``.
+        ``choose``: the pixel subset as an input (tests: the reference's own draw) instead of the device-side sampling."""
         rgb, depth, lab2d, info, target, model_points, add_t = host
         rmin, rmax, cmin, cmax, count, oi = (int(v) for v in info.tolist())
         if count == 0:
@@ -226,7 +227,7 @@ class PoseDataset:
         up = lambda t: t.to(dev, non_blocking=True)            # asynchronous when the loader pinned `t`, staged otherwise
         img, cloud, choose, _ = pp.preprocess_objects(up(rgb)[None], up(depth)[None], up(lab2d)[None],
                                                       [(0, 255, (rmin, rmax, cmin, cmax), (self.seed * 1000003 + int(index)) & 0xFFFFFFFF)],
-                                                      self.num, cam=pp.LINEMOD_CAM)
+                                                      self.num, cam=pp.LINEMOD_CAM, choose_in=choose)
         idx = torch.tensor([oi], dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
         idx._host = [oi]
         if self.add_noise:

@@ -143,8 +143,9 @@ class PoseDataset:
                 torch.tensor([cam[k] for k in ("cx", "cy", "fx", "fy", "scale")] + list(add_t if self.add_noise else np.zeros(3)), dtype=torch.float64),
                 torch.from_numpy(target.astype(np.float32)), torch.from_numpy(model_points.astype(np.float32)))
 
-    def device_item(self, index, host):
-        """Device half: uploads + one preparation launch on the current stream.  The 6-tuple of ``__getitem__``."""
+    def device_item(self, index, host, choose=None):
+        """Device half: uploads + one preparation launch on the current stream.  The 6-tuple of ``__getitem__``.
+        ``choose``: the pixel subset as an input (tests: the reference's own draw) instead of the device-side sampling."""
         rgb, depth, label, info, camv, target, model_points = host
         rmin, rmax, cmin, cmax, cls, syn = (int(v) for v in info.tolist())
         camv = camv.tolist()
@@ -153,7 +154,7 @@ class PoseDataset:
         up = lambda t: t.to(dev, non_blocking=True)            # asynchronous when the loader pinned `t`, staged otherwise
         img, cloud, choose, _count = pp.preprocess_objects(up(rgb)[None], up(depth)[None], up(label)[None],
                                                            [(0, cls, (rmin, rmax, cmin, cmax), (self.seed * 1000003 + int(index)) & 0xFFFFFFFF)],
-                                                           self.num_pt, cam=cam)
+                                                           self.num_pt, cam=cam, choose_in=choose)
         if any(add_t):                                       # :196-197 (the same translation went into the target)
             cloud = cloud + torch.tensor(add_t, dtype=torch.float32, device=dev)
         if syn:                                               # :166-167 N(0, 7) on the 0-255-scale pixels = N(0, 7 / std) after the normalisation

@@ -46,9 +46,11 @@ def get_bbox(roi, img_width=IMG_WIDTH, img_length=IMG_LENGTH):
     return rmin, rmax, cmin, cmax
 
 
-def preprocess_objects(rgb, depth, label, objects, num_points, cam=YCB_CAM):
+def preprocess_objects(rgb, depth, label, objects, num_points, cam=YCB_CAM, choose_in=None):
     """rgb [F,IH,IW,3] uint8, depth [F,IH,IW] uint16 (as int16 bits is fine), label [F,IH,IW] int32 -- device tensors.
     objects: list of (frame, itemid, (rmin, rmax, cmin, cmax), seed), all boxes of one size.
+    choose_in (optional, [B,N] / [B,1,N] int64): the chosen pixel indices as an INPUT (sampling skipped) -- the reference's own
+    np.random.shuffle subset in the golden tests.
     Returns img [B,3,H,W], cloud [B,N,3], choose [B,1,N] int64, count [B] int32 (0 = lost detection)."""
     if not (rgb.is_cuda and depth.is_cuda and label.is_cuda):
         raise RuntimeError("densefusion_amd needs device tensors (no CPU path)")
@@ -64,6 +66,7 @@ def preprocess_objects(rgb, depth, label, objects, num_points, cam=YCB_CAM):
             raise RuntimeError("preprocess_objects: box outside the frame")
         desc[i, :6] = (frame, itemid, rmin, rmax, cmin, cmax)
         desc[i, 6] = np.array([seed & 0xFFFFFFFF], dtype=np.uint32).view(np.int32)[0]      # uint32 seed bits
+        desc[i, 7] = 1 if choose_in is not None else 0
     dev = rgb.device
     d_desc = torch.from_numpy(desc).pin_memory().to(dev, non_blocking=True)      # pinned: the upload does not wait for the stream
     rgb, label = rgb.contiguous(), label.to(torch.int32).contiguous()
@@ -73,7 +76,10 @@ def preprocess_objects(rgb, depth, label, objects, num_points, cam=YCB_CAM):
     scratch = torch.empty(B * H * W, dtype=torch.int32, device=dev)
     img = torch.empty(B, 3, H, W, device=dev)
     cloud = torch.empty(B, num_points, 3, device=dev)
-    choose = torch.empty(B, 1, num_points, dtype=torch.int64, device=dev)
+    if choose_in is not None:
+        choose = choose_in.to(device=dev, dtype=torch.int64).reshape(B, 1, num_points).contiguous().clone()
+    else:
+        choose = torch.empty(B, 1, num_points, dtype=torch.int64, device=dev)
     count = torch.empty(B, dtype=torch.int32, device=dev)
     with _lib.device_guard(dev):
         st = _lib.lib().df_preprocess_objects(rgb.data_ptr(), depth.data_ptr(), label.data_ptr(), F, IH, IW, d_desc.data_ptr(), B,

@@ -212,6 +212,10 @@ class NativeTrainer:
                                       [bool(fr[j]["symmetric"]) for j in order], w, dropout=dropout, seed=seed)
         return out, order
 
+    def set_splitk(self, enable):
+        """Split-K of the small-grid launches (default on).  Off: a frame's gradient no longer depends on what shares its pass."""
+        _lib.check(_lib.lib().df_trainer_set_splitk(self._h, int(bool(enable))), "trainer_set_splitk")
+
     # ---- executed-FLOP profile of the step's MFMA launches (df_trainer_profile) ----
     def profile(self, enable=True):
         _lib.check(_lib.lib().df_trainer_profile(self._h, int(bool(enable))), "trainer_profile")

@@ -196,7 +196,9 @@ int df_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
  * subset / wrap-padding); back-projected cloud; ImageNet-normalised CHW crop.  B objects of one crop size
  * (H x W) per call.
  *   rgb [F][IH][IW][3] u8, depth [F][IH][IW] u16, label [F][IH][IW] i32 (F frames resident on the device)
- *   obj_desc [B][8] int32 = {frame, itemid, rmin, rmax, cmin, cmax, seed, 0}; rmax-rmin == H, cmax-cmin == W
+ *   obj_desc [B][8] int32 = {frame, itemid, rmin, rmax, cmin, cmax, seed, given}; rmax-rmin == H, cmax-cmin == W;
+ *   given != 0: the object's row of choose_out is an INPUT -- the caller's chosen pixel indices (how a test hands over the very subset
+ *   the reference's np.random.shuffle drew); sampling is skipped, cloud / img are formed from those indices
  *   scratch: B*H*W int32.  Outputs: img_out [B][3][H][W], cloud_out [B][N][3], choose_out [B][N] int64,
  *   count_out [B] = number of mask pixels (0 = detector lost the object, eval_ycb.py:234-237).
  * Subset rule when count > N (replaces np.random.shuffle, whose stream a GPU cannot share): keep the N mask
@@ -232,6 +234,11 @@ typedef struct df_conv_desc {
   size_t splitk_ws_bytes;
 } df_conv_desc;
 int df_conv2d_nhwc(const df_conv_desc *d, df_stream_t stream);
+/* The same convolution over nb crop-size buckets in ONE launch (the training step's direct k x k convolutions on a window of mixed crop
+ * sizes): bucket i = B[i] maps of H[i] x W[i] (host arrays); the buckets' pixel rows are concatenated in bucket order in d->in, d->out and
+ * d->res; d->B / H / W / OH / OW are ignored.  A workgroup's output tile lies inside one bucket; per output element the same sums in the same
+ * order as a df_conv2d_nhwc call on that bucket alone without split-K: bit-identical. */
+int df_conv2d_nhwc_multi(const df_conv_desc *d, int nb, const int *B, const int *H, const int *W, df_stream_t stream);
 /* number of K ranges the calling thread's last df_conv2d_nhwc / df_conv2d_dgrad_nhwc launch was cut into (1 = not split): tests */
 int df_conv_last_splitk(void);
 
@@ -262,6 +269,11 @@ int df_conv2d_dgrad_nhwc(const df_conv_desc *d, const float *dy, float *dx, floa
 size_t df_conv2d_wgrad_workspace_bytes(const df_conv_desc *d);
 int df_conv2d_wgrad_nhwc(const df_conv_desc *d, const float *dy, float *dw, float *db, void *ws, size_t ws_bytes,
                          df_stream_t stream);
+/* Weight gradient of df_conv2d_nhwc_multi: ONE contraction over the pixels of all buckets (bucket layout as there; dy rows concatenated like
+ * d->out), dw / db overwritten; fixed-order reduction: bit-reproducible. */
+size_t df_conv2d_wgrad_multi_workspace_bytes(const df_conv_desc *d, int nb, const int *B, const int *H, const int *W);
+int df_conv2d_wgrad_nhwc_multi(const df_conv_desc *d, int nb, const int *B, const int *H, const int *W, const float *dy, float *dw, float *db,
+                               void *ws, size_t ws_bytes, df_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Native training step (replaces the loop body of tools/train.py:146-163 of the reference: estimator / refiner forward,
@@ -314,6 +326,10 @@ int df_posenet_train_step_multi(df_trainer *t, const float *flat_param, float *f
  * it; after the stream has been synchronised df_trainer_profile_read fills, per kind (0 forward, 1 data gradient, 2 weight gradient), the
  * summed launch durations in ms, the FLOPs the launches EXECUTE (2 M N K of the shapes really run, not the reference graph's) and the
  * launch counts since arming, and re-arms. */
+/* Split-K of the small-grid forward / data-gradient launches of a step (default on: faster one-frame passes; results then depend on a
+ * launch's grid size through fp32 re-association, and ReLU-gated gradients amplify that to ~1e-3 of a tensor's scale).  Off: every output
+ * element is summed in one order whatever else shares the pass. */
+int df_trainer_set_splitk(df_trainer *t, int enable);
 int df_trainer_profile(df_trainer *t, int enable);
 int df_trainer_profile_read(df_trainer *t, double *ms3, double *flops3, int *launches3);
 size_t df_refiner_train_workspace_bytes(const df_trainer *t, int B, int M);

@@ -346,3 +346,71 @@ def test_splitk_convolution(geom):
     s2 = max(1.0, float(want_dx.abs().max()))
     assert float((outs[1].double() - want_dx).abs().max()) <= 3e-5 * s2
     assert float((outs[0].double() - want_dx).abs().max()) <= 3e-5 * s2
+
+
+def _multi_desc(x, w, out, stride, pad, dil, act=0, bias=None, res=None):
+    import ctypes
+    from densefusion_amd import _lib
+    d = _lib.ConvDesc()
+    d.in_, d.wgt, d.out = x.data_ptr(), w.data_ptr(), (out.data_ptr() if out is not None else None)
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.res = res.data_ptr() if res is not None else None
+    d.Cin, d.in_ld, d.in_coff = w.shape[-1], x.shape[-1], 0
+    d.Cout, d.out_ld, d.out_coff = w.shape[0], w.shape[0], 0
+    d.res_ld, d.res_coff = (res.shape[-1] if res is not None else 0), 0
+    d.KH, d.KW, d.stride, d.pad, d.dil, d.act = w.shape[1], w.shape[2], stride, pad, dil, act
+    return d
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,dil,act,use_res", [(64, 64, 3, 1, 1, 1, 1, True), (64, 128, 3, 2, 1, 1, 1, False), (64, 128, 1, 2, 0, 1, 0, False),
+                                                                   (4, 64, 7, 2, 3, 1, 1, False), (512, 512, 3, 1, 4, 4, 1, True), (128, 128, 3, 1, 2, 2, 0, False)])
+def test_multi_bucket_convolution_is_bit_identical_to_per_bucket_launches(cin, cout, k, stride, pad, dil, act, use_res):
+    """df_conv2d_nhwc_multi (csrc/igemm.hip igemm_f32_v4_multi_kernel): several crop-size buckets -- different map sizes and batch
+    counts, pixel rows concatenated -- in ONE launch equal one df_conv2d_nhwc launch per bucket (no split-K) bit for bit; and the
+    multi-bucket weight gradient equals the fp64 reference of the summed per-bucket gradients."""
+    import ctypes
+    from densefusion_amd import _lib
+    from densefusion_amd.ops import conv2d_nhwc
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(cin * 7 + cout + k)
+    sizes = [(2, 10, 20), (1, 40, 40), (1, 20, 20), (3, 7, 9), (1, 30, 40)]
+    if cin >= 512:
+        sizes = [(2, 5, 10), (1, 20, 20), (1, 10, 10), (1, 15, 20)]
+    w = (torch.randn(cout, k, k, cin, generator=g) * 0.05).cuda()
+    bias = torch.randn(cout, generator=g).cuda()
+    xs = [torch.randn(b, h, wd, cin, generator=g).cuda() for b, h, wd in sizes]
+    oh = lambda v: (v + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    ress = [torch.randn(b, oh(h), oh(wd), cout, generator=g).cuda() for b, h, wd in sizes] if use_res else [None] * len(sizes)
+    want = [conv2d_nhwc(x, w, bias, stride=stride, pad=pad, dil=dil, act=act, res=r) for x, r in zip(xs, ress)]        # ops.conv2d_nhwc passes no split-K scratch here
+    xcat = torch.cat([x.reshape(-1, cin) for x in xs]).contiguous()
+    rcat = torch.cat([r.reshape(-1, cout) for r in ress]).contiguous() if use_res else None
+    rows_out = sum(t.shape[0] * t.shape[1] * t.shape[2] for t in want)
+    out = torch.full((rows_out, cout), float("nan"), device="cuda")
+    d = _multi_desc(xcat, w, out, stride, pad, dil, act, bias, rcat)
+    arr = ctypes.c_int * len(sizes)
+    cB, cH, cW = arr(*[s[0] for s in sizes]), arr(*[s[1] for s in sizes]), arr(*[s[2] for s in sizes])
+    _lib.check(L.df_conv2d_nhwc_multi(ctypes.byref(d), len(sizes), cB, cH, cW, _lib.current_stream()), "conv2d_nhwc_multi")
+    got = out.cpu()
+    ref = torch.cat([t.reshape(-1, cout) for t in want]).cpu()
+    assert torch.equal(got, ref), f"max diff {(got - ref).abs().max().item():.3e}"
+    # weight gradient over all buckets in one contraction vs fp64
+    dy = torch.randn(rows_out, cout, generator=g).cuda()
+    dw, db = torch.empty_like(w), torch.empty(cout, device="cuda")
+    d.out = None
+    need = L.df_conv2d_wgrad_multi_workspace_bytes(ctypes.byref(d), len(sizes), cB, cH, cW)
+    ws = torch.empty(max(int(need), 4), dtype=torch.uint8, device="cuda")
+    _lib.check(L.df_conv2d_wgrad_nhwc_multi(ctypes.byref(d), len(sizes), cB, cH, cW, dy.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            _lib.current_stream()), "conv2d_wgrad_multi")
+    dw_ref = torch.zeros(cout, cin, k, k, dtype=torch.float64)
+    r0 = 0
+    for x, (b, h, wd) in zip(xs, sizes):
+        n = b * oh(h) * oh(wd)
+        gy = dy[r0:r0 + n].reshape(b, oh(h), oh(wd), cout).permute(0, 3, 1, 2).double().cpu()
+        xin = x.permute(0, 3, 1, 2).double().cpu()
+        dw_ref += torch.nn.grad.conv2d_weight(xin, (cout, cin, k, k), gy, stride=stride, padding=pad, dilation=dil)
+        r0 += n
+    dw_ref = dw_ref.permute(0, 2, 3, 1)
+    scale = dw_ref.abs().max().item()
+    assert (dw.cpu().double() - dw_ref).abs().max().item() <= 2e-5 * scale
+    db_ref = dy.double().sum(0).cpu()
+    assert (db.cpu().double() - db_ref).abs().max().item() <= 2e-5 * db_ref.abs().max().item()

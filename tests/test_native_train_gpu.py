@@ -374,11 +374,16 @@ def test_refiner_step_at_the_ycb_refine_mesh_size():
 
 def test_a_window_of_mixed_crop_sizes_as_one_pass_equals_the_sum_of_its_one_frame_passes():
     """df_posenet_train_step_multi: frames of DIFFERENT crop sizes in one pass (what real data gives, tools/train.py:131-176 of the
-    reference trains on whatever crop each frame has).  Per parameter tensor, the gradient of the window equals the sum of the
-    frames' bs = 1 passes up to fp32 summation order: <= 2e-5 of the tensor's largest gradient (NOT bit-identical: one contraction over
-    all frames' pixels adds in another order than frame-by-frame accumulation; measured 1e-7 .. 3e-6); per-frame outputs
-    (loss, dis, re-centred clouds) likewise.  Two identical multi-bucket passes are bit-identical, dropout on.  Covers a bucket with two
-    frames, symmetric and plain objects, a crop the F(4x4,3x3) route takes (160 x 160) and ones it does not."""
+    reference trains on whatever crop each frame has).  NOT bit-identical to the frames' bs = 1 passes -- one contraction over all
+    frames' pixels adds in another order than frame-by-frame accumulation -- but equal up to fp32 summation order:
+      * with split-K off (df_trainer_set_splitk: every output element summed in one order whatever shares the pass) every parameter
+        tensor's gradient is within 5e-6 of its largest entry of the sum of the one-frame passes (measured worst 4.3e-7; whole-buffer
+        relative L2 1.1e-7), per-frame outputs (loss, dis, re-centred clouds, emb) within 2e-5;
+      * with the default split-K the one-frame passes split their small grids and the window does not: the ReLU-gated backward
+        amplifies that re-association to 4e-3 of a tensor's scale at worst (layer4.1.conv2: 900 pixels), 3e-4 relative L2 over the
+        buffer -- the same level as B same-size frames per pass against one per pass (test above: 5e-4) -- bounded here at 2e-2 / 2e-3.
+    Two identical multi-bucket passes are bit-identical, dropout on.  Covers a bucket with two frames, symmetric and plain objects, a crop
+    the F(4x4,3x3) route takes (160 x 160) and ones it does not."""
     K, N, M = 3, 128, 60
     sizes = [(40, 80), (160, 160), (80, 80), (40, 80), (120, 160)]
     sd = synth.make_state_dict(synth.posenet_spec(K), 23)
@@ -389,29 +394,33 @@ def test_a_window_of_mixed_crop_sizes_as_one_pass_equals_the_sum_of_its_one_fram
                    obj=torch.from_numpy(o["obj"]).to(DEV), target=torch.from_numpy(o["target"]).to(DEV), model_points=torch.from_numpy(o["model_points"]).to(DEV),
                    symmetric=int(o["obj"][0]) == 1) for o in objs]
     tr = _trainer("posenet", N, K, sd)
-    out, order = tr.step_posenet_window(frames, 0.015, dropout=False)
-    assert sorted(order) == list(range(len(frames))) and order[:2] == [0, 3]          # the two 40 x 80 frames share a bucket
-    g_multi = tr.grad_dict()
-    flat_multi = tr.grad.clone()
-    tr.zero_grad()
-    for row, j in enumerate(order):
-        f = frames[j]
-        o1 = tr.step_posenet(f["img"][None], f["cloud"][None], f["choose"].reshape(1, -1), f["obj"].reshape(1), f["target"][None], f["model_points"][None],
-                             [f["symmetric"]], 0.015, dropout=False)
-        for k in ("loss", "dis", "new_points", "new_target", "emb"):
-            _close(out[k][row:row + 1], o1[k], 2e-5, k)
-    g_single = tr.grad_dict()
-    worst = 0.0
-    for k, v in g_single.items():
-        if "classifier" in k:
-            assert float(g_multi[k].abs().max()) == 0.0          # dead weights (lib/pspnet.py:58-62) receive no gradient
-            continue
-        scale = max(float(v.abs().max()), 1e-12)
-        err = float((g_multi[k] - v).abs().max()) / scale
-        worst = max(worst, err)
-        assert err <= 2e-5, f"{k}: window vs sum of one-frame passes {err:.2e} of the tensor's scale"
-    print(f"mixed window vs one-frame passes: worst per-tensor deviation {worst:.2e} of scale")
-    _close(flat_multi, tr.grad, 2e-5, "flat gradient buffer")
+    for splitk, tol_tensor, tol_l2 in ((False, 5e-6, 2e-6), (True, 2e-2, 2e-3)):
+        tr.set_splitk(splitk)
+        tr.zero_grad()
+        out, order = tr.step_posenet_window(frames, 0.015, dropout=False)
+        assert sorted(order) == list(range(len(frames))) and order[:2] == [0, 3]          # the two 40 x 80 frames share a bucket
+        g_multi = tr.grad_dict()
+        tr.zero_grad()
+        for row, j in enumerate(order):
+            f = frames[j]
+            o1 = tr.step_posenet(f["img"][None], f["cloud"][None], f["choose"].reshape(1, -1), f["obj"].reshape(1), f["target"][None], f["model_points"][None],
+                                 [f["symmetric"]], 0.015, dropout=False)
+            for k in ("loss", "dis", "new_points", "new_target", "emb"):
+                _close(out[k][row:row + 1], o1[k], 2e-5, k)
+        g_single = tr.grad_dict()
+        worst, num, den = 0.0, 0.0, 0.0
+        for k, v in g_single.items():
+            if "classifier" in k:
+                assert float(g_multi[k].abs().max()) == 0.0          # dead weights (lib/pspnet.py:58-62) receive no gradient
+                continue
+            scale = max(float(v.abs().max()), 1e-12)
+            err = float((g_multi[k] - v).abs().max()) / scale
+            worst = max(worst, err)
+            num += float(((g_multi[k] - v).double() ** 2).sum()); den += float((v.double() ** 2).sum())
+            assert err <= tol_tensor, f"split-K {splitk}: {k}: window vs sum of one-frame passes {err:.2e} of the tensor's scale"
+        l2 = (num / den) ** 0.5
+        print(f"mixed window vs one-frame passes, split-K {splitk}: worst per-tensor deviation {worst:.2e} of scale, relative L2 {l2:.2e}")
+        assert l2 <= tol_l2
     runs = []
     for _ in range(2):
         tr.zero_grad()
