@@ -25,6 +25,9 @@
 #include <type_traits>
 
 // DF_TRACE(i): per-workgroup time stamps for tools/dev/igemm_trace.hip (compiles this file with the hook defined); nothing otherwise
+#ifndef DF_WTRACE
+#define DF_WTRACE(i)      // the same for the weight-gradient kernel (tools/dev/wgrad_trace.hip)
+#endif
 #ifndef DF_TRACE
 #define DF_TRACE(i)
 #define DF_TRACE_WAVE_END(w)
@@ -1086,6 +1089,11 @@ struct WgTab {
   long in_row0[WGRAD_MAX_SEGS], out_row0[WGRAD_MAX_SEGS];
 };
 
+// Workgroups per CU of the big kernel (144 registers: no spill).  Measured on the training step's 18 shapes (tools/dev/wgrad_shapes.py) with
+// the pixel split sized for one round: 2 / 3 / 4 per CU = 76.0 / 78.2 / 76.4 TFLOP/s in total -- occupancy is not what bounds it: per
+// workgroup the main loop keeps the matrix pipe 95 % busy (tools/dev/wgrad_trace.hip); what is left is the prologue's first loads, the
+// 64 KB partial tile every workgroup stores and the reduce launch behind it.
+constexpr int WGRAD_OCC = 3;
 template <int TN_, int OCC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void wgrad_f32_v2_kernel(const ConvParams p, float *__restrict__ part, int m_chunk, int split,
                                                                                                           const WgTab tab) {
@@ -1184,25 +1192,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   const int li = lane & 31, lh = lane >> 5;
   const int fy = lh * LDY + wn * (TN_ / 2) + li, fa = OPY + lh * LDA + wk * 64 + li;
+  DF_WTRACE(0);
   if (nt > 0) {
     issue_loads(0);
     write_lds();
     issue_loads(1);
   }
   __syncthreads();
+  DF_WTRACE(1);
   for (int t = 0; t < nt; ++t) {
     const float *base = smem;
-#pragma unroll
-    for (int s = 0; s < RM / 2; ++s) {
-      float a[NI];
+    // fragments of pixel pair s + 1 are fetched (into their own registers) before pair s multiplies: with one register set the
+    // compiler serialised read -> wait -> 4 MFMAs -> read, and every pair paid the LDS latency
+    float fa_[2][NI], fb_[2][2];
+    auto frag = [&](int s, float (&a)[NI], float (&b)[2]) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) a[i] = base[fy + s * 2 * LDY + i * 32];
-      const float b0 = base[fa + s * 2 * LDA], b1 = base[fa + s * 2 * LDA + 32];
+      b[0] = base[fa + s * 2 * LDA]; b[1] = base[fa + s * 2 * LDA + 32];
+    };
+    frag(0, fa_[0], fb_[0]);
+#pragma unroll
+    for (int s = 0; s < RM / 2; ++s) {
+      if (s + 1 < RM / 2) frag(s + 1, fa_[(s + 1) & 1], fb_[(s + 1) & 1]);
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b0, acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b1, acc[i][1], 0, 0, 0);
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[s & 1][i], fb_[s & 1][0], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[s & 1][i], fb_[s & 1][1], acc[i][1], 0, 0, 0);
       }
+      // keep the order written here: the next pair's LDS reads are issued, THEN this pair's MFMAs (hipcc otherwise sinks the reads
+      // behind the MFMAs and reuses one register set)
+      if (s + 1 < RM / 2) __builtin_amdgcn_sched_group_barrier(0x100, NI == 2 ? 2 : 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NI, 0);
     }
     // ONE LDS tile per workgroup (4 workgroups per CU instead of the 2 a double buffer allows: the other three cover this hand-over);
     // the next chunk has been in flight in registers for the whole tile
@@ -1213,6 +1233,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     }
     __syncthreads();
   }
+  DF_WTRACE(2);
   float *dst = part + (size_t)zz * p.Cout * K;
 #pragma unroll
   for (int i = 0; i < NI; ++i)
@@ -1223,6 +1244,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         const int n = n0 + wn * (TN_ / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, k = k0 + wk * 64 + j * 32 + li;
         if (n < p.Cout && k < K) dst[(size_t)n * K + k] = acc[i][j][e];
       }
+  DF_WTRACE(3);
 }
 
 // dw[i] = sum_z part[z][i], bit-reproducible: 8 z-lanes per output vector each add their slices z = l, l + 8, ... in ascending
@@ -1556,9 +1578,8 @@ WgradPlan wgrad_plan(const ConvParams &p, int nseg, const WgradSeg *segs) {
   w.big = p.Cout >= 64 && K >= 128;
   const int tn = w.big && p.Cout >= 128 ? 128 : 64, tk = w.big ? 128 : 64;
   w.tiles = ((p.Cout + tn - 1) / tn) * ((K + tk - 1) / tk);
-  // split the pixel range so that one round of workgroups (4 per CU: 1024) is in flight, each with at least 256 pixels
-  static const long slots = getenv("DF_WGRAD_SLOTS") ? atol(getenv("DF_WGRAD_SLOTS")) : 1024;      // TEMPORARY A/B switch
-  long split = slots / w.tiles;
+  // split the pixel range so that one round of workgroups (WGRAD_OCC per CU) is in flight, each with at least 256 pixels
+  long split = (256 * WGRAD_OCC) / w.tiles;
   const long max_split = (M + 255) / 256;
   if (split > max_split) split = max_split;
   if (split > 256) split = 256;          // (the partial slices are re-read by the reduction)
@@ -1620,28 +1641,20 @@ static int launch_wgrad_segs(ConvParams p, int nseg, const WgradSeg *segs, float
       tab.z0[g + 1] = tab.z0[g] + (int)((Mg + w.chunk - 1) / w.chunk);
     }
     constexpr size_t lds128 = (size_t)32 * (132 + 132) * 4, lds64 = (size_t)32 * (68 + 132) * 4;
-    static const int occ = getenv("DF_WGRAD_OCC") ? atoi(getenv("DF_WGRAD_OCC")) : 2;      // TEMPORARY A/B switch
-    auto go = [&](auto tn, auto oc, size_t lds) {
-      constexpr int TN = decltype(tn)::value, OC = decltype(oc)::value;
+    auto go = [&](auto tn, size_t lds) {
+      constexpr int TN = decltype(tn)::value;
       static bool attr_done[64] = {};
       int dev = 0;
       hipGetDevice(&dev);
       if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_f32_v2_kernel<TN, OC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_f32_v2_kernel<TN, WGRAD_OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done[dev] = true;
       }
-      hipLaunchKernelGGL((wgrad_f32_v2_kernel<TN, OC>), dim3((unsigned)(w.tiles * w.split)), dim3(256), lds, st, p, part, w.chunk, w.split, tab);
+      hipLaunchKernelGGL((wgrad_f32_v2_kernel<TN, WGRAD_OCC>), dim3((unsigned)(w.tiles * w.split)), dim3(256), lds, st, p, part, w.chunk, w.split, tab);
     };
     using std::integral_constant;
-    if (p.Cout >= 128) {
-      if (occ == 4) go(integral_constant<int, 128>{}, integral_constant<int, 4>{}, lds128);
-      else if (occ == 3) go(integral_constant<int, 128>{}, integral_constant<int, 3>{}, lds128);
-      else go(integral_constant<int, 128>{}, integral_constant<int, 2>{}, lds128);
-    } else {
-      if (occ == 4) go(integral_constant<int, 64>{}, integral_constant<int, 4>{}, lds64);
-      else if (occ == 3) go(integral_constant<int, 64>{}, integral_constant<int, 3>{}, lds64);
-      else go(integral_constant<int, 64>{}, integral_constant<int, 2>{}, lds64);
-    }
+    if (p.Cout >= 128) go(integral_constant<int, 128>{}, lds128);
+    else go(integral_constant<int, 64>{}, lds64);
   } else {
     // the small-shape kernel decodes one geometry: one launch per bucket into consecutive partial slices
     int z = 0;

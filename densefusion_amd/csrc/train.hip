@@ -365,6 +365,388 @@ __global__ __launch_bounds__(TB) void up3_patch_bwd_kernel(const float *__restri
   *reinterpret_cast<f32x4 *>(dU + (((size_t)b * h + qy) * wd + qx) * 64 + c4 * 4) = acc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Memory-bound kernels over ALL crop-size buckets of a level in one launch: a bucket table travels in the kernel arguments, an element
+// finds its bucket by a scan of <= 16 row bounds (the buckets' pixel rows are concatenated, bucket g = B[g] maps of H[g] x W[g] from
+// row row0[g]; its frames are b0[g] .. of the pass).  Same arithmetic per element as the per-bucket kernels above.
+// ------------------------------------------------------------------------------------------------
+constexpr int TAB_MAX = 16;
+struct BTab {
+  int n;
+  int B[TAB_MAX], H[TAB_MAX], W[TAB_MAX], b0[TAB_MAX];
+  long row0[TAB_MAX], row1[TAB_MAX];      // first pixel row, one past the last
+  long aux0[TAB_MAX];                     // first row of the bucket in a second level (pooled / convolved maps), where a kernel needs one
+};
+__device__ inline int tab_of_row(const BTab &t, long row) {
+  int g = 0;
+  while (g + 1 < t.n && row >= t.row1[g]) ++g;
+  return g;
+}
+__device__ inline int tab_of_frame(const BTab &t, int frame) {
+  int g = 0;
+  while (g + 1 < t.n && frame >= t.b0[g + 1]) ++g;
+  return g;
+}
+
+// y[r][c] = x[r][c] * scale[frame(r)][c]  (Dropout2d and its adjoint)
+__global__ __launch_bounds__(TB) void channel_scale_multi_kernel(const float *__restrict__ x, int x_ld, const float *__restrict__ scale, float *__restrict__ y,
+                                                                 int y_ld, int C4, const BTab tab) {
+  const long r_lo = tab.row0[0], nrow = tab.row1[tab.n - 1] - r_lo;
+  GRID_STRIDE(i, nrow * C4) {
+    const long r = r_lo + i / C4;
+    const int c = (int)(i % C4) * 4;
+    const int g = tab_of_row(tab, r);
+    const int frame = tab.b0[g] + (int)((r - tab.row0[g]) / ((long)tab.H[g] * tab.W[g]));
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * x_ld + c), sc = *reinterpret_cast<const f32x4 *>(scale + (size_t)frame * C4 * 4 + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = v[e] * sc[e];
+    *reinterpret_cast<f32x4 *>(y + r * y_ld + c) = o;
+  }
+}
+
+// AdaptiveAvgPool2d adjoint of the FOUR pyramid stages (sizes 1, 2, 3, 6) at once: dx[pix] (+)= sum_s sum over the stage's bins that contain
+// the pixel of dy_s[frame][bin] / |bin| (stages ascending, bins row-major: a fixed order); dy_s = [frames][s*s][C] blocks
+struct Ptr4 { const float *p[4]; };
+struct MPtr4 { float *p[4]; };
+__global__ __launch_bounds__(TB) void pool_bwd_all_kernel(const Ptr4 dy, float *__restrict__ dx, int dx_ld, int C4, int accumulate, const BTab tab) {
+  const long r_lo = tab.row0[0], nrow = tab.row1[tab.n - 1] - r_lo;
+  GRID_STRIDE(i, nrow * C4) {
+    const long r = r_lo + i / C4;
+    const int c4 = (int)(i % C4);
+    const int g = tab_of_row(tab, r);
+    const int H = tab.H[g], W = tab.W[g];
+    long l = r - tab.row0[g];
+    const int xx = (int)(l % W); l /= W;
+    const int yy = (int)(l % H);
+    const int frame = tab.b0[g] + (int)(l / H);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int si = 0; si < 4; ++si) {
+      const int s = si == 0 ? 1 : si == 1 ? 2 : si == 2 ? 3 : 6;
+      const float *d = dy.p[si] + (size_t)frame * s * s * C4 * 4;
+      for (int bi = max(0, yy * s / H - 1); bi <= min(s - 1, yy * s / H + 1); ++bi) {
+        const int y0 = (bi * H) / s, y1 = ((bi + 1) * H + s - 1) / s;
+        if (yy < y0 || yy >= y1) continue;
+        for (int bj = max(0, xx * s / W - 1); bj <= min(s - 1, xx * s / W + 1); ++bj) {
+          const int x0 = (bj * W) / s, x1 = ((bj + 1) * W + s - 1) / s;
+          if (xx < x0 || xx >= x1) continue;
+          const f32x4 v = reinterpret_cast<const f32x4 *>(d)[(size_t)(bi * s + bj) * C4 + c4];
+          const float cnt = (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += v[e] / cnt;
+        }
+      }
+    }
+    float *o = dx + r * dx_ld + c4 * 4;
+    if (accumulate) {
+      const f32x4 old = *reinterpret_cast<const f32x4 *>(o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = old[e] + acc[e];
+    }
+    *reinterpret_cast<f32x4 *>(o) = acc;
+  }
+}
+
+// the four pyramid priors (bilinear, align_corners = False, lib/pspnet.py:22) of every bucket: y[r][si * C + c] from z_si [frames][s*s][C]
+__global__ __launch_bounds__(TB) void bilinear_fwd_all_kernel(const Ptr4 z, float *__restrict__ y, int y_ld, int C4, const BTab tab) {
+  const long r_lo = tab.row0[0], nrow = tab.row1[tab.n - 1] - r_lo;
+  GRID_STRIDE(i, nrow * 4 * C4) {
+    const int c4 = (int)(i % C4);
+    const int si = (int)((i / C4) % 4);
+    const long r = r_lo + i / (4 * C4);
+    const int g = tab_of_row(tab, r);
+    const int OH = tab.H[g], OW = tab.W[g];
+    long l = r - tab.row0[g];
+    const int ox = (int)(l % OW); l /= OW;
+    const int oy = (int)(l % OH);
+    const int frame = tab.b0[g] + (int)(l / OH);
+    const int s = si == 0 ? 1 : si == 1 ? 2 : si == 2 ? 3 : 6;
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    bil_src(oy, s, OH, 0, y0, y1, wy0, wy1);
+    bil_src(ox, s, OW, 0, x0, x1, wx0, wx1);
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(z.p[si]) + (size_t)frame * s * s * C4 + c4;
+    const f32x4 v00 = p[(size_t)(y0 * s + x0) * C4], v01 = p[(size_t)(y0 * s + x1) * C4], v10 = p[(size_t)(y1 * s + x0) * C4], v11 = p[(size_t)(y1 * s + x1) * C4];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = wy0 * (wx0 * v00[e] + wx1 * v01[e]) + wy1 * (wx0 * v10[e] + wx1 * v11[e]);
+    *reinterpret_cast<f32x4 *>(y + r * y_ld + (size_t)si * C4 * 4 + c4 * 4) = o;
+  }
+}
+
+// their adjoint, all four stages and all buckets: job = (stage, frame, stage pixel q, group of 8 channel vectors); 32 pixel lanes per output
+// like bilinear_bwd_kernel (same candidate order, same fixed reduction); dz_si = [frames][s*s][C]
+__global__ __launch_bounds__(TB) void bilinear_bwd_all_kernel(const float *__restrict__ dy, int dy_ld, const MPtr4 dz, int frames, int C4, const BTab tab) {
+  __shared__ f32x4 s_p[32][8];
+  const int col = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int cgroups = (C4 + 7) / 8;
+  const long per_frame = 50L * cgroups;                   // 1 + 4 + 9 + 36 stage pixels
+  for (long job = blockIdx.x; job < (long)frames * per_frame; job += gridDim.x) {
+    const int frame = tab.b0[0] + (int)(job / per_frame);          // (`frames` counts the table's frames; dz / dy are indexed by the absolute frame)
+    long rem = job - (job / per_frame) * per_frame;
+    const int cg = (int)(rem % cgroups);
+    int q = (int)(rem / cgroups);
+    int si = 0, s = 1;
+    if (q >= 14) { si = 3; s = 6; q -= 14; } else if (q >= 5) { si = 2; s = 3; q -= 5; } else if (q >= 1) { si = 1; s = 2; q -= 1; }
+    const int qy = q / s, qx = q - qy * s;
+    const int g = tab_of_frame(tab, frame);
+    const int OH = tab.H[g], OW = tab.W[g];
+    const float *src = dy + (tab.row0[g] + (long)(frame - tab.b0[g]) * OH * OW) * dy_ld + (size_t)si * C4 * 4;
+    const int c4 = cg * 8 + col;
+    int ylo, yhi, xlo, xhi;
+    bil_cands(qy, s, OH, 0, ylo, yhi);
+    bil_cands(qx, s, OW, 0, xlo, xhi);
+    const int nx = xhi - xlo + 1, total = (yhi - ylo + 1) * nx;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < C4)
+      for (int idx = pl; idx < total; idx += 32) {
+        const int oy = ylo + idx / nx, ox = xlo + idx % nx;
+        int y0, y1, x0, x1;
+        float wy0, wy1, wx0, wx1;
+        bil_src(oy, s, OH, 0, y0, y1, wy0, wy1);
+        if (y0 != qy && y1 != qy) continue;
+        bil_src(ox, s, OW, 0, x0, x1, wx0, wx1);
+        if (x0 != qx && x1 != qx) continue;
+        const float wy = (y0 == qy ? wy0 : 0.f) + (y1 == qy ? wy1 : 0.f);
+        const float wx = (x0 == qx ? wx0 : 0.f) + (x1 == qx ? wx1 : 0.f);
+        const f32x4 gv = *reinterpret_cast<const f32x4 *>(src + ((long)oy * OW + ox) * dy_ld + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += (wy * wx) * gv[e];
+      }
+    s_p[pl][col] = acc;
+    __syncthreads();
+    if (pl == 0 && c4 < C4) {
+#pragma unroll 4
+      for (int l = 1; l < 32; ++l)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += s_p[l][col][e];
+      reinterpret_cast<f32x4 *>(dz.p[si])[((size_t)frame * s * s + q) * C4 + c4] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+// upconv_gather_bwd_kernel over all buckets: g rows live at the upsampled level (4 x the low-resolution rows of each bucket)
+__global__ __launch_bounds__(TB) void upconv_gather_bwd_multi_kernel(const float *__restrict__ gsrc, float *__restrict__ dY, int Cout, const BTab tab) {
+  const int C4 = Cout / 4;
+  const long r_lo = tab.row0[0], nrow = tab.row1[tab.n - 1] - r_lo;
+  GRID_STRIDE(i, nrow * 9 * C4) {
+    const int c = (int)(i % C4) * 4;
+    long r = i / C4;
+    const int tap = (int)(r % 9); r /= 9;
+    const long row = r_lo + r;
+    const int gi = tab_of_row(tab, row);
+    const int h = tab.H[gi], w = tab.W[gi], OH = 2 * h, OW = 2 * w;
+    long l = row - tab.row0[gi];
+    const int qx = (int)(l % w); l /= w;
+    const int qy = (int)(l % h);
+    const int b = (int)(l / h);
+    const float *g = gsrc + 4 * tab.row0[gi] * Cout;
+    const int dy = tap / 3, dx = tap - dy * 3;
+    int ylo, yhi, xlo, xhi;
+    bil_cands(qy, h, OH, 1, ylo, yhi);
+    bil_cands(qx, w, OW, 1, xlo, xhi);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int uy = ylo; uy <= yhi; ++uy) {
+      const int py = uy - dy + 1;
+      if ((unsigned)py >= (unsigned)OH) continue;
+      int y0, y1;
+      float wy0, wy1;
+      bil_src(uy, h, OH, 1, y0, y1, wy0, wy1);
+      if (y0 != qy && y1 != qy) continue;
+      const float wy = (y0 == qy ? wy0 : 0.f) + (y1 == qy ? wy1 : 0.f);
+      for (int ux = xlo; ux <= xhi; ++ux) {
+        const int px = ux - dx + 1;
+        if ((unsigned)px >= (unsigned)OW) continue;
+        int x0, x1;
+        float wx0, wx1;
+        bil_src(ux, w, OW, 1, x0, x1, wx0, wx1);
+        if (x0 != qx && x1 != qx) continue;
+        const float wx = (x0 == qx ? wx0 : 0.f) + (x1 == qx ? wx1 : 0.f);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(g + ((long)(b * OH + py) * OW + px) * Cout + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += (wy * wx) * v[e];
+      }
+    }
+    reinterpret_cast<f32x4 *>(dY)[(row * 9 + tap) * C4 + c / 4] = acc;
+  }
+}
+
+// MaxPool2d(3, stride 2, pad 1) adjoint over all buckets (trainops.hip maxpool3s2_bwd_kernel: first-maximum rule); tab = the INPUT level,
+// aux0 = the buckets' first rows at the pooled level
+__global__ __launch_bounds__(TB) void maxpool3s2_bwd_multi_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx, int C,
+                                                                  const BTab tab) {
+  const long r_lo = tab.row0[0], nrow = tab.row1[tab.n - 1] - r_lo;
+  GRID_STRIDE(i, nrow * C) {
+    const int c = (int)(i % C);
+    const long row = r_lo + i / C;
+    const int g = tab_of_row(tab, row);
+    const int H = tab.H[g], W = tab.W[g], OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    long l = row - tab.row0[g];
+    const int ix = (int)(l % W); l /= W;
+    const int iy = (int)(l % H);
+    const int b = (int)(l / H);
+    const float *xb = x + (tab.row0[g] + (long)b * H * W) * C + c;
+    const float *dyb = dy + (tab.aux0[g] + (long)b * OH * OW) * C + c;
+    const float xv = xb[((long)iy * W + ix) * C];
+    float acc = 0.f;
+    for (int oy = (iy + 1) / 2 - 1 < 0 ? 0 : (iy + 1) / 2 - 1; oy <= (iy + 1) / 2 && oy < OH; ++oy) {
+      if (iy < oy * 2 - 1 || iy > oy * 2 + 1) continue;
+      for (int ox = (ix + 1) / 2 - 1 < 0 ? 0 : (ix + 1) / 2 - 1; ox <= (ix + 1) / 2 && ox < OW; ++ox) {
+        if (ix < ox * 2 - 1 || ix > ox * 2 + 1) continue;
+        bool win = true;
+        for (int ky = 0; ky < 3 && win; ++ky) {
+          const int yy = oy * 2 - 1 + ky;
+          if ((unsigned)yy >= (unsigned)H) continue;
+          for (int kx = 0; kx < 3; ++kx) {
+            const int xx = ox * 2 - 1 + kx;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            const float v = xb[((long)yy * W + xx) * C];
+            const bool earlier = yy < iy || (yy == iy && xx < ix);
+            if (v > xv || (earlier && v == xv)) { win = false; break; }
+          }
+        }
+        if (win) acc += dyb[((long)oy * OW + ox) * C];
+      }
+    }
+    dx[row * C + c] = acc;
+  }
+}
+
+// Data gradient of a STRIDED convolution from its per-tap products (col2im as a gather): dcol[m][tap * C + c] = sum_n dY[m][n] w[n][tap][c]
+// for every output pixel m (one GEMM over the rows of all buckets); an input pixel collects the <= ceil(k / stride)^2 (tap, output pixel)
+// pairs that read it, taps in row-major order (fixed order).  tab = the INPUT level, aux0 = the buckets' first rows at the output level.
+__global__ __launch_bounds__(TB) void col2im_multi_kernel(const float *__restrict__ dcol, float *__restrict__ dx, int dx_ld, int C, int k, int stride, int pad,
+                                                          int dil, int accumulate, const BTab tab) {
+  const int C4 = C / 4;
+  const long r_lo = tab.row0[0], nrow = tab.row1[tab.n - 1] - r_lo;
+  GRID_STRIDE(i, nrow * C4) {
+    const int c4 = (int)(i % C4);
+    const long row = r_lo + i / C4;
+    const int g = tab_of_row(tab, row);
+    const int H = tab.H[g], W = tab.W[g];
+    const int OH = (H + 2 * pad - dil * (k - 1) - 1) / stride + 1, OW = (W + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+    long l = row - tab.row0[g];
+    const int ix = (int)(l % W); l /= W;
+    const int iy = (int)(l % H);
+    const int b = (int)(l / H);
+    const float *src = dcol + (tab.aux0[g] + (long)b * OH * OW) * (size_t)(k * k * C);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < k; ++ky) {
+      const int ty = iy + pad - ky * dil;
+      if (ty < 0 || ty % stride) continue;
+      const int oy = ty / stride;
+      if (oy >= OH) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int tx = ix + pad - kx * dil;
+        if (tx < 0 || tx % stride) continue;
+        const int ox = tx / stride;
+        if (ox >= OW) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + ((long)oy * OW + ox) * (size_t)(k * k * C) + (size_t)(ky * k + kx) * C + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+      }
+    }
+    float *o = dx + row * dx_ld + c4 * 4;
+    if (accumulate) {
+      const f32x4 old = *reinterpret_cast<const f32x4 *>(o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = old[e] + acc[e];
+    }
+    *reinterpret_cast<f32x4 *>(o) = acc;
+  }
+}
+
+// the three up_3 patch-adjoint kernels over all buckets (tab = the half-resolution level; frames of all buckets in one grid, rows / columns
+// beyond a bucket's map exit): row lists and counts are laid out with the LARGEST map height hmax per frame
+__global__ __launch_bounds__(TB) void up3_decode_multi_kernel(const int64_t *__restrict__ choose, int4 *__restrict__ tabo, int frames, int N, const BTab tab) {
+  GRID_STRIDE(i, (long)frames * N) {          // (choose / tabo start at the table's first frame)
+    const int g = tab_of_frame(tab, tab.b0[0] + (int)(i / N));
+    const int h = tab.H[g], wd = tab.W[g];
+    const int OH = 2 * h, OW = 2 * wd, HW = OH * OW;
+    long pix = choose[i];
+    pix = pix < 0 ? 0 : (pix >= HW ? HW - 1 : pix);
+    const int py = (int)(pix / OW), px = (int)(pix % OW);
+    int i0, i1, rlo, rhi, clo, chi;
+    float l0, l1;
+    bil_src(max(py - 1, 0), h, OH, 1, rlo, i1, l0, l1);
+    bil_src(min(py + 1, OH - 1), h, OH, 1, i0, rhi, l0, l1);
+    bil_src(max(px - 1, 0), wd, OW, 1, clo, i1, l0, l1);
+    bil_src(min(px + 1, OW - 1), wd, OW, 1, i0, chi, l0, l1);
+    tabo[i] = make_int4(py | (px << 16), rlo | (rhi << 16), clo | (chi << 16), 0);
+  }
+}
+__global__ __launch_bounds__(TB) void up3_rowlist_multi_kernel(const int4 *__restrict__ tabi, int *__restrict__ rows, int *__restrict__ cnt, int hmax, int N,
+                                                               const BTab tab) {
+  __shared__ int s_w[4];
+  const int b = blockIdx.y, qy = blockIdx.x;          // b: frame relative to the table's first (tabi / rows / cnt start there)
+  if (qy >= tab.H[tab_of_frame(tab, tab.b0[0] + b)]) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int *out = rows + ((size_t)b * hmax + qy) * N;
+  int base = 0;
+  for (int n0 = 0; n0 < N; n0 += TB) {
+    const int n = n0 + threadIdx.x;
+    bool hit = false;
+    if (n < N) {
+      const int4 e = tabi[(size_t)b * N + n];
+      hit = qy >= (e.y & 0xffff) && qy <= (e.y >> 16);
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    int before = base;
+    for (int w2 = 0; w2 < wave; ++w2) before += s_w[w2];
+    if (hit) out[before + __popcll(m & ((1ull << lane) - 1ull))] = n;
+    base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cnt[b * hmax + qy] = base;
+}
+__global__ __launch_bounds__(TB) void up3_patch_bwd_multi_kernel(const float *__restrict__ dpatch, const int4 *__restrict__ tabi, const int *__restrict__ rows,
+                                                                 const int *__restrict__ cnt, float *__restrict__ dU, int hmax, int N, int Npad, const BTab tab) {
+  const int b = blockIdx.z, qy = blockIdx.y;          // b: frame relative to the table's first (dpatch / tabi / rows / cnt start there)
+  const int g = tab_of_frame(tab, tab.b0[0] + b);
+  const int h = tab.H[g], wd = tab.W[g];
+  const int OH = 2 * h, OW = 2 * wd;
+  const int c4 = threadIdx.x & 15, qx = blockIdx.x * (TB / 16) + (threadIdx.x >> 4);
+  if (qy >= h || qx >= wd) return;
+  const int *list = rows + ((size_t)b * hmax + qy) * N;
+  const int count = cnt[b * hmax + qy];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < count; ++i) {
+    const int j = list[i];
+    const int4 e4 = tabi[(size_t)b * N + j];
+    if (qx < (e4.z & 0xffff) || qx > (e4.z >> 16)) continue;
+    const float *row = dpatch + ((size_t)b * Npad + j) * 576 + c4 * 4;
+    const int py = e4.x & 0xffff, px = e4.x >> 16;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int uy = py + dy - 1;
+      if ((unsigned)uy >= (unsigned)OH) continue;
+      int y0, y1;
+      float wy0, wy1;
+      bil_src(uy, h, OH, 1, y0, y1, wy0, wy1);
+      if (y0 != qy && y1 != qy) continue;
+      const float wy = (y0 == qy ? wy0 : 0.f) + (y1 == qy ? wy1 : 0.f);
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ux = px + dx - 1;
+        if ((unsigned)ux >= (unsigned)OW) continue;
+        int x0, x1;
+        float wx0, wx1;
+        bil_src(ux, wd, OW, 1, x0, x1, wx0, wx1);
+        if (x0 != qx && x1 != qx) continue;
+        const float wx = (x0 == qx ? wx0 : 0.f) + (x1 == qx ? wx1 : 0.f);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(row + (dy * 3 + dx) * 64);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += (wy * wx) * v[e];
+      }
+    }
+  }
+  *reinterpret_cast<f32x4 *>(dU + (tab.row0[g] + ((long)(tab.b0[0] + b - tab.b0[g]) * h + qy) * wd + qx) * 64 + c4 * 4) = acc;
+}
+
 // Conv1d(3, 64, 1) on the cloud (lib/network.py:54): partial sums of dW [64][3], db [64] over a chunk of 64 points;
 // g = the masked gradient of its output, a [B*Npad][64] view.  part[chunk][64][4] = (dW_x, dW_y, dW_z, db)
 __global__ __launch_bounds__(64) void cloud_conv1_bwd_kernel(const float *__restrict__ g, int g_ld, const float *__restrict__ cloud, int B, int N,
@@ -751,7 +1133,8 @@ void build_posenet(Trainer &t) {
     for (int blk = 0; blk < 2; ++blk) {
       const int cin = blk == 0 ? inpl : planes;
       const std::string base = c + "feats.layer" + std::to_string(li) + "." + std::to_string(blk) + ".";
-      add_conv(t, base + "conv1.weight", planes, cin, 3);
+      // (a strided convolution's data gradient goes through per-tap products + a gather: it multiplies with the plain transpose)
+      add_conv(t, base + "conv1.weight", planes, cin, 3, false, blk == 0 && li == 2);
       add_conv(t, base + "conv2.weight", planes, planes, 3);
       if (blk == 0 && cin != planes) add_conv(t, base + "downsample.0.weight", planes, cin, 1);
     }
@@ -982,6 +1365,25 @@ ConvParams flat_params(const Act *x, int cin, const float *w, const float *bias,
   p.act = act;
   return p;
 }
+// bucket tables of a level, TAB_MAX buckets each (aux: a second level whose first rows go into aux0)
+std::vector<BTab> make_tabs(const Lv *lv, const Lv *aux = nullptr) {
+  std::vector<BTab> out;
+  for (int g0 = 0; g0 < lv->nb(); g0 += TAB_MAX) {
+    BTab t{};
+    t.n = std::min(TAB_MAX, lv->nb() - g0);
+    for (int i = 0; i < TAB_MAX; ++i) {
+      const int g = g0 + std::min(i, t.n - 1);           // (entries past n repeat the last bucket: never selected)
+      t.B[i] = lv->B[g]; t.H[i] = lv->H[g]; t.W[i] = lv->W[g]; t.b0[i] = lv->b0[g];
+      t.row0[i] = lv->off[g]; t.row1[i] = lv->off[g] + (long)lv->B[g] * lv->H[g] * lv->W[g];
+      t.aux0[i] = aux ? aux->off[g] : 0;
+    }
+    out.push_back(t);
+  }
+  return out;
+}
+inline long tab_rows(const BTab &t) { return t.row1[t.n - 1] - t.row0[0]; }
+inline int tab_frames(const BTab &t) { return t.b0[t.n - 1] + t.B[t.n - 1] - t.b0[0]; }
+
 // bucket i of a k x k convolution between two levels
 ConvParams bucket_params(const Act *x, int i, int cin, const float *w, const float *bias, Act *y, int k, int stride, int pad, int dil, int act) {
   ConvParams p;
@@ -1156,7 +1558,25 @@ Act *conv(Step &s, Act *x, int cin, const ConvW &cw, int cout, int k, int stride
           for (int j : *f4) on_f4 |= j == i;
           if (!on_f4) direct.push_back(i);
         }
-        if (direct.size() == 1 || stride != 1)        // (a strided convolution's data gradient reads a dilated input: the un-pipelined kernel, per bucket)
+        if (stride != 1) {
+          // strided: dcol[m][tap * cin + c] = sum_n dY[m][n] w[n][tap][c] for every OUTPUT pixel m -- one GEMM over the rows of all buckets
+          // against the plain transpose of the packed weights -- then every input pixel gathers the (tap, output pixel) pairs that read it
+          // (col2im_multi_kernel).  (The dilated-input form of the direct kernel multiplies 3/4 zeros at stride 2 and runs per bucket.)
+          const int kk = k * k * cin;
+          const size_t mark = s.off;
+          float *dcol = s.f((size_t)lo->rows * kk);
+          ConvParams q;
+          q.in = y->g.d; q.B = (int)lo->rows; q.Cin = cout; q.in_ld = y->g.ld;
+          q.wgt = s.pf(cw.name, cw.woff);
+          q.out = dcol; q.Cout = kk; q.out_ld = kk;
+          q.splitk_ws = s.splitk; q.splitk_ws_bytes = s.splitk_bytes;
+          s.gemm(GK_DGRAD, q);
+          if (s.live())
+            for (const BTab &t : make_tabs(li, lo))
+              hipLaunchKernelGGL(col2im_multi_kernel, dim3(nblk(tab_rows(t) * (cin / 4))), dim3(TB), 0, s.st, dcol, x->g.d, x->g.ld, cin, k, stride, pad, dil,
+                                 acc ? 1 : 0, t);
+          s.off = mark;
+        } else if (direct.size() == 1)
           for (int i : direct) dgrad(s, (*plan)[i], rows_view(y->g, lo->off[i]), rows_view(x->g, li->off[i]), s.pf(cw.name, cw.woff), acc);
         else if (!direct.empty()) {
           const ConvParams &f = (*plan)[0];
@@ -1244,20 +1664,19 @@ Act *dropout2d(Step &s, Act *a, float p, unsigned seed) {
   const Lv *lv = a->lv;
   float *scale = s.f((size_t)lv->frames * a->C);
   Act *o = s.act(lv, a->C);
+  const std::vector<BTab> tabs = make_tabs(lv);
   if (s.live()) {
     s.fail(df_dropout2d_mask(scale, (int64_t)lv->frames * a->C, seed, p, s.st));
-    for (int i = 0; i < lv->nb(); ++i)
-      s.fail(df_channel_scale(a->v.d + lv->off[i] * a->v.ld, scale + (size_t)lv->b0[i] * a->C, o->v.d + lv->off[i] * o->v.ld, lv->B[i],
-                              (int64_t)lv->H[i] * lv->W[i], a->C, s.st));
+    for (const BTab &t : tabs)
+      hipLaunchKernelGGL(channel_scale_multi_kernel, dim3(nblk(tab_rows(t) * (a->C / 4))), dim3(TB), 0, s.st, a->v.d, a->v.ld, scale, o->v.d, o->v.ld, a->C / 4, t);
   }
   Step *sp = &s;
   s.tape.push_back([=]() {
     Step &s = *sp;
     s.grad_of(a);
     if (s.live())
-      for (int i = 0; i < lv->nb(); ++i)
-        s.fail(df_channel_scale(o->g.d + lv->off[i] * o->g.ld, scale + (size_t)lv->b0[i] * a->C, a->g.d + lv->off[i] * a->g.ld, lv->B[i],
-                                (int64_t)lv->H[i] * lv->W[i], a->C, s.st));
+      for (const BTab &t : tabs)
+        hipLaunchKernelGGL(channel_scale_multi_kernel, dim3(nblk(tab_rows(t) * (a->C / 4))), dim3(TB), 0, s.st, o->g.d, o->g.ld, scale, a->g.d, a->g.ld, a->C / 4, t);
   });
   return o;
 }
@@ -1295,9 +1714,8 @@ Act *upconv(Step &s, Act *x, const std::string &base, int cin, int cout) {
     }
     s.grad_of(y);
     if (s.live())
-      for (int i = 0; i < nb; ++i)
-        hipLaunchKernelGGL(upconv_gather_bwd_kernel, dim3(nblk((long)li->B[i] * li->H[i] * li->W[i] * 9 * (cout / 4))), dim3(TB), 0, s.st,
-                           o->g.d + lo->off[i] * cout, y->g.d + li->off[i] * 9 * cout, li->B[i], li->H[i], li->W[i], cout);
+      for (const BTab &t : make_tabs(li))
+        hipLaunchKernelGGL(upconv_gather_bwd_multi_kernel, dim3(nblk(tab_rows(t) * 9 * (cout / 4))), dim3(TB), 0, s.st, o->g.d, y->g.d, cout, t);
     wgrad(s, p, y->g, s.gr(cw.name), nullptr);
     const bool acc = s.grad_of(x);
     dgrad(s, p, y->g, x->g, s.pf(cw.name), acc);
@@ -1336,9 +1754,8 @@ void posenet_step(Step &s, const PoseNetIO &io) {
       Step &s = *sp;
       s.grad_of(stem);
       if (s.live())
-        for (int i = 0; i < nb; ++i)
-          s.fail(df_maxpool3s2_bwd(stem->v.d + ls->off[i] * 64, xp->g.d + lx->off[i] * xp->g.ld, stem->g.d + ls->off[i] * 64, ls->B[i], ls->H[i], ls->W[i], 64,
-                                   lx->H[i], lx->W[i], s.st));
+        for (const BTab &t : make_tabs(ls, lx))
+          hipLaunchKernelGGL(maxpool3s2_bwd_multi_kernel, dim3(nblk(tab_rows(t) * 64)), dim3(TB), 0, s.st, stem->v.d, xp->g.d, stem->g.d, 64, t);
     });
   }
   int cin = 64;
@@ -1365,33 +1782,39 @@ void posenet_step(Step &s, const PoseNetIO &io) {
   if (s.live())
     for (int i = 0; i < nb; ++i)
       launch_psp_pool(feat->v.d + l8->off[i] * feat->v.ld, feat->v.ld, 0, pyr, l8->B[i], l8->H[i], l8->W[i], 512, s.st, B, l8->b0[i]);
+  struct Stages { Act *pooled[4], *z[4]; };
+  auto stg = std::make_shared<Stages>();
+  const std::vector<BTab> tabs8 = make_tabs(l8);
+  s.tape.push_back([=]() {          // (pushed first: runs after the four stage convolutions' backward) the pooling adjoint of all stages, all buckets
+    Step &s = *sp;
+    const bool acc = s.grad_of(feat);
+    Ptr4 dy;
+    for (int si = 0; si < 4; ++si) dy.p[si] = stg->pooled[si]->g.d;
+    if (s.live())
+      for (const BTab &t : tabs8)
+        hipLaunchKernelGGL(pool_bwd_all_kernel, dim3(nblk(tab_rows(t) * 128)), dim3(TB), 0, s.st, dy, feat->g.d, feat->g.ld, 128, acc ? 1 : 0, t);
+  });
   for (int si = 0; si < 4; ++si) {
     const int sz = si == 0 ? 1 : si == 1 ? 2 : si == 2 ? 3 : 6;
-    Act *pooled = s.act((long)B * sz * sz, 512, pyr + (size_t)si * B * 36 * 512, 512);
-    s.tape.push_back([=]() {
-      Step &s = *sp;
-      const bool acc = s.grad_of(feat);
-      if (s.live())
-        for (int i = 0; i < nb; ++i)
-          hipLaunchKernelGGL(pool_bwd_kernel, dim3(nblk((long)l8->B[i] * l8->H[i] * l8->W[i] * 128)), dim3(TB), 0, s.st,
-                             pooled->g.d + (size_t)l8->b0[i] * sz * sz * 512, feat->g.d + l8->off[i] * feat->g.ld, feat->g.ld, l8->B[i], l8->H[i], l8->W[i], 128, sz,
-                             acc ? 1 : 0);
-    });
-    Act *z = conv(s, pooled, 512, ConvW{C + "psp.stages." + std::to_string(si) + ".1.weight"}, 512, 1, 1, 0, 1, ACT_NONE);
-    Act *prior = slice(s, cat, 512 * si, 512);
-    if (s.live())
-      for (int i = 0; i < nb; ++i)
-        hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(nblk((long)l8->B[i] * l8->H[i] * l8->W[i] * 128)), dim3(TB), 0, s.st, z->v.d + (size_t)l8->b0[i] * sz * sz * 512,
-                           prior->v.d + l8->off[i] * prior->v.ld, prior->v.ld, l8->B[i], sz, sz, 128, l8->H[i], l8->W[i], 0);
-    s.tape.push_back([=]() {
-      Step &s = *sp;
-      s.grad_of(z);
-      if (s.live())
-        for (int i = 0; i < nb; ++i)
-          hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)((long)l8->B[i] * sz * sz * 16)), dim3(TB), 0, s.st, cat->g.d + l8->off[i] * cat->g.ld + 512 * si,
-                             cat->g.ld, z->g.d + (size_t)l8->b0[i] * sz * sz * 512, l8->B[i], sz, sz, 128, l8->H[i], l8->W[i], 0);
-    });
+    stg->pooled[si] = s.act((long)B * sz * sz, 512, pyr + (size_t)si * B * 36 * 512, 512);
+    stg->z[si] = conv(s, stg->pooled[si], 512, ConvW{C + "psp.stages." + std::to_string(si) + ".1.weight"}, 512, 1, 1, 0, 1, ACT_NONE);
   }
+  {
+    Ptr4 z;
+    for (int si = 0; si < 4; ++si) z.p[si] = stg->z[si]->v.d;
+    if (s.live())
+      for (const BTab &t : tabs8)
+        hipLaunchKernelGGL(bilinear_fwd_all_kernel, dim3(nblk(tab_rows(t) * 4 * 128)), dim3(TB), 0, s.st, z, cat->v.d, cat->v.ld, 128, t);
+  }
+  s.tape.push_back([=]() {          // (runs before the stage convolutions' backward) the four resampling adjoints in one launch
+    Step &s = *sp;
+    MPtr4 dz;
+    for (int si = 0; si < 4; ++si) { s.grad_of(stg->z[si]); dz.p[si] = stg->z[si]->g.d; }
+    if (s.live())
+      for (const BTab &t : tabs8)
+        hipLaunchKernelGGL(bilinear_bwd_all_kernel, dim3((unsigned)std::min<long>((long)tab_frames(t) * 50 * 16, 65535L * 16)), dim3(TB), 0, s.st, cat->g.d, cat->g.ld,
+                           dz, tab_frames(t), 128, t);
+  });
   // the concat's gradient buffer is one allocation; layer4's output gradient is its last 512 channels
   s.tape.push_back([=]() {
     feat->g.d = cat->g.d + 2048;
@@ -1414,17 +1837,19 @@ void posenet_step(Step &s, const PoseNetIO &io) {
   s.tape.push_back([=]() {
     Step &s = *sp;
     s.grad_of(u2);
-    for (int i = 0; i < nb; ++i) {
-      const int Bi = l2->B[i], h = l2->H[i], wd = l2->W[i];
+    int hmax = 0, wmax = 0;
+    for (int i = 0; i < nb; ++i) { hmax = std::max(hmax, l2->H[i]); wmax = std::max(wmax, l2->W[i]); }
+    for (const BTab &t : make_tabs(l2)) {
+      const int fr = tab_frames(t), f0 = t.b0[0];
       const size_t mark = s.off;
-      int4 *tab = reinterpret_cast<int4 *>(s.bytes((size_t)Bi * N * sizeof(int4)));
-      int *rowlist = reinterpret_cast<int *>(s.bytes((size_t)Bi * h * N * sizeof(int)));
-      int *rowcnt = reinterpret_cast<int *>(s.bytes((size_t)Bi * h * sizeof(int)));
+      int4 *tabo = reinterpret_cast<int4 *>(s.bytes((size_t)fr * N * sizeof(int4)));
+      int *rowlist = reinterpret_cast<int *>(s.bytes((size_t)fr * hmax * N * sizeof(int)));
+      int *rowcnt = reinterpret_cast<int *>(s.bytes((size_t)fr * hmax * sizeof(int)));
       if (s.live()) {
-        hipLaunchKernelGGL(up3_decode_kernel, dim3(nblk((long)Bi * N)), dim3(TB), 0, s.st, io.choose + (size_t)l2->b0[i] * N, tab, Bi, h, wd, N);
-        hipLaunchKernelGGL(up3_rowlist_kernel, dim3(h, Bi), dim3(TB), 0, s.st, tab, rowlist, rowcnt, h, N);
-        hipLaunchKernelGGL(up3_patch_bwd_kernel, dim3((wd + TB / 16 - 1) / (TB / 16), h, Bi), dim3(TB), 0, s.st, patch->g.d + (size_t)l2->b0[i] * Npad * 576, tab,
-                           rowlist, rowcnt, u2->g.d + l2->off[i] * 64, h, wd, N, Npad);
+        hipLaunchKernelGGL(up3_decode_multi_kernel, dim3(nblk((long)fr * N)), dim3(TB), 0, s.st, io.choose + (size_t)f0 * N, tabo, fr, N, t);
+        hipLaunchKernelGGL(up3_rowlist_multi_kernel, dim3(hmax, fr), dim3(TB), 0, s.st, tabo, rowlist, rowcnt, hmax, N, t);
+        hipLaunchKernelGGL(up3_patch_bwd_multi_kernel, dim3((wmax + TB / 16 - 1) / (TB / 16), hmax, fr), dim3(TB), 0, s.st, patch->g.d + (size_t)f0 * Npad * 576, tabo,
+                           rowlist, rowcnt, u2->g.d, hmax, N, Npad, t);
       }
       s.off = mark;
     }

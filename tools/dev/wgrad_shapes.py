@@ -9,6 +9,8 @@ SHAPES = [  # B, H, W, Cin, Cout, k, pad, dil, stride
     (8, 20, 20, 2560, 1024, 1, 0, 1, 1), (8, 40, 40, 1024, 256, 3, 1, 1, 1), (8, 80, 80, 256, 64, 3, 1, 1, 1), (8, 160, 160, 64, 64, 3, 1, 1, 1),
     (8, 160, 160, 64, 32, 1, 0, 1, 1), (8, 1000, 1, 512, 1024, 1, 0, 1, 1), (8, 1000, 1, 1408, 640, 1, 0, 1, 1), (8, 1000, 1, 640, 256, 1, 0, 1, 1),
     (8, 1000, 1, 64, 128, 1, 0, 1, 1), (8, 1000, 1, 256, 512, 1, 0, 1, 1)]
+if len(sys.argv) > 1:
+    SHAPES = [SHAPES[int(a)] for a in sys.argv[1:]]
 tot_us = tot_fl = 0
 for (B, H, W, Cin, Cout, k, pad, dil, stride) in SHAPES:
     x = torch.randn(B, H, W, Cin, device="cuda")
