@@ -1078,15 +1078,18 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const ConvParams p, floa
 // (pixels beyond the chunk, padding taps, ragged Cout / K) is a bounds-checked buffer load that returns 0.
 // ------------------------------------------------------------------------------------------------
 // Several crop-size buckets in one launch (WgTab, by value): the pixel rows of the buckets are concatenated in p.in / p.out, bucket g is
-// tab.in_rows[g] input pixels from row tab.in_row0[g] and tab.M[g] output pixels from row tab.out_row0[g]; a workgroup's pixel chunk
-// (blockIdx.z) lies inside ONE bucket (chunks z0[g] .. z0[g + 1]), so the im2col decode uses that bucket's map size.
+// tab.in_rows[g] input pixels from row tab.in_row0[g] and tab.M[g] output pixels from row tab.out_row0[g].  The contraction axis is cut
+// into STEPS of 32 pixels that never straddle buckets (a bucket's last step is ragged: its missing rows load zeros); the steps of all
+// buckets form one sequence (bucket g = steps step0[g] .. step0[g + 1]) that is cut into equal chunks of `steps_per_chunk`, one per
+// workgroup -- so a window of mixed crop sizes costs what the same pixels in one size would.  A workgroup walks its steps with the
+// current bucket's geometry in scalar registers and reloads it when a step crosses into the next bucket.
 struct WgTab {
   int n;
-  int z0[WGRAD_MAX_SEGS + 1];
-  int H[WGRAD_MAX_SEGS], W[WGRAD_MAX_SEGS], OW[WGRAD_MAX_SEGS], ohw[WGRAD_MAX_SEGS], M[WGRAD_MAX_SEGS], in_rows[WGRAD_MAX_SEGS];
+  int step0[WGRAD_MAX_SEGS + 1];
+  int H[WGRAD_MAX_SEGS], W[WGRAD_MAX_SEGS], OW[WGRAD_MAX_SEGS], ohw[WGRAD_MAX_SEGS], M[WGRAD_MAX_SEGS];
   unsigned ohw_magic[WGRAD_MAX_SEGS], ow_magic[WGRAD_MAX_SEGS];
   int ohw_sh[WGRAD_MAX_SEGS], ow_sh[WGRAD_MAX_SEGS];
-  long in_row0[WGRAD_MAX_SEGS], out_row0[WGRAD_MAX_SEGS];
+  unsigned in_off[WGRAD_MAX_SEGS], out_off[WGRAD_MAX_SEGS];      // byte offsets of the bucket's first input / output row
 };
 
 // Workgroups per CU of the big kernel (144 registers: no spill).  Measured on the training step's 18 shapes (tools/dev/wgrad_shapes.py) with
@@ -1095,8 +1098,8 @@ struct WgTab {
 // 64 KB partial tile every workgroup stores and the reduce launch behind it.
 constexpr int WGRAD_OCC = 3;
 template <int TN_, int OCC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void wgrad_f32_v2_kernel(const ConvParams p, float *__restrict__ part, int m_chunk, int split,
-                                                                                                          const WgTab tab) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void wgrad_f32_v2_kernel(const ConvParams p, float *__restrict__ part, int steps_per_chunk, int split,
+                                                                                                          unsigned in_bytes, unsigned out_bytes, const WgTab tab) {
   static_assert(TN_ == 64 || TN_ == 128, "n side of the tile");
   constexpr int TK_ = 128, RM = 32;
   constexpr int LDY = TN_ + 4, LDA = TK_ + 4;        // row strides: the second pixel of a step lands 4 banks further (2-way at worst)
@@ -1125,19 +1128,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     const int T = p.KH * p.KW, cb = kt / T, tap = kt - cb * T;
     kt = tap * (p.Cin / TK_) + cb;
   }
-  int sg = 0;
-  while (sg + 1 < tab.n && zz >= tab.z0[sg + 1]) ++sg;      // (workgroup-uniform: scalar loads of the table)
-  const int M = tab.M[sg];
-  const int sH = tab.H[sg], sW = tab.W[sg], sOW = tab.OW[sg];
-  const unsigned ohw_magic = tab.ohw_magic[sg], ow_magic = tab.ow_magic[sg];
-  const int ohw_sh = tab.ohw_sh[sg], ow_sh = tab.ow_sh[sg];
   const int n0 = n_blk * TN_, k0 = kt * TK_;
-  const int m_begin = (zz - tab.z0[sg]) * m_chunk, m_end = min(M, m_begin + m_chunk);
-  const int nt = (m_end - m_begin + RM - 1) / RM;
+  const int step_begin = zz * steps_per_chunk, step_end = min(tab.step0[tab.n], step_begin + steps_per_chunk);
+  const int nt = step_end - step_begin;
+  // the current bucket's geometry (workgroup-uniform: scalar registers), reloaded when a step enters the next bucket
+  int sg = 0;
+  while (sg + 1 < tab.n && step_begin >= tab.step0[sg + 1]) ++sg;
+  int M, sH, sW, sOW, ohw, ohw_sh, ow_sh, seg_step0, seg_step1;
+  unsigned ohw_magic, ow_magic, so_x, so_y;
+  auto load_seg = [&]() {
+    M = tab.M[sg]; sH = tab.H[sg]; sW = tab.W[sg]; sOW = tab.OW[sg]; ohw = tab.ohw[sg];
+    ohw_magic = tab.ohw_magic[sg]; ow_magic = tab.ow_magic[sg]; ohw_sh = tab.ohw_sh[sg]; ow_sh = tab.ow_sh[sg];
+    so_x = tab.in_off[sg]; so_y = tab.out_off[sg];
+    seg_step0 = tab.step0[sg]; seg_step1 = tab.step0[sg + 1];
+  };
+  load_seg();
 
-  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in) + tab.in_row0[sg] * p.in_ld, 0,
-                                                      (unsigned)((size_t)tab.in_rows[sg] * p.in_ld * sizeof(float)), 0x00020000);
-  const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.out + tab.out_row0[sg] * p.out_ld, 0, (unsigned)((size_t)M * p.out_ld * sizeof(float)), 0x00020000);
+  // one descriptor per operand over all buckets; a bucket's base travels in the loads' scalar offset (total bytes < 4 GB: host-checked)
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, in_bytes, 0x00020000);
+  const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes, 0x00020000);
 
   // loader of the A tile: this thread stages channel vector `vec` (4 floats) of the rows lrow + 8 i
   const int vec = tid & 31, lrow = tid >> 5;
@@ -1154,26 +1163,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   const int yvec = tid % VY, yrow = tid / VY;
   const int ncol = n0 + yvec * 4;
   const bool nok = ncol < p.Cout;
-  const int ohw = tab.ohw[sg];
   u32x4 ry[PY], ra[4];
   auto issue_loads = [&](int t) {
+    const int st = step_begin + t;                      // (steps are requested in increasing order)
+    const bool live = st < step_end;
+    if (live && st >= seg_step1) {
+      while (sg + 1 < tab.n && st >= tab.step0[sg + 1]) ++sg;
+      load_seg();
+    }
+    const int m0 = (st - seg_step0) * RM;               // first pixel of the step inside its bucket
 #pragma unroll
     for (int i = 0; i < PY; ++i) {
-      const int m = m_begin + t * RM + yrow + RPY * i;
-      unsigned o = (m < m_end && nok) ? (unsigned)(m * p.out_ld + p.out_coff + ncol) * 4u : 0xffffffffu;
+      const int m = m0 + yrow + RPY * i;
+      unsigned o = (live && m < M && nok) ? (unsigned)(m * p.out_ld + p.out_coff + ncol) * 4u : 0xffffffffu;
       asm("" : "+v"(o));
-      ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, o, 0, 0);
+      ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, o, (int)so_y, 0);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = m_begin + t * RM + lrow + 8 * i;
+      const int m = m0 + lrow + 8 * i;
       const int b = fdiv(m, ohw_magic, ohw_sh, ohw), rem = m - b * ohw;
       const int oy = fdiv(rem, ow_magic, ow_sh, sOW), ox = rem - oy * sOW;
       const int iy = oy * p.stride - p.pad + dyy, ix = ox * p.stride - p.pad + dxx;
-      const bool aok = m < m_end && kok && (unsigned)iy < (unsigned)sH && (unsigned)ix < (unsigned)sW;
+      const bool aok = live && m < M && kok && (unsigned)iy < (unsigned)sH && (unsigned)ix < (unsigned)sW;
       unsigned o = aok ? (unsigned)(((b * sH + iy) * sW + ix) * p.in_ld + p.in_coff + c) * 4u : 0xffffffffu;
       asm("" : "+v"(o));
-      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, o, 0, 0);
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, o, (int)so_x, 0);
     }
   };
   auto write_lds = [&]() {
@@ -1567,13 +1582,18 @@ int launch_conv_multi(const ConvParams &p, int nseg, const WgradSeg *segs, hipSt
 }
 
 namespace {
-struct WgradPlan { bool big; int tiles, split, chunk, nblk; size_t part_floats, bias_floats; };
+struct WgradPlan { bool big; int tiles, split, chunk, steps, nblk; size_t part_floats, bias_floats; };
 
-// `M`: pixels of the whole contraction; `chunks_of`: chunks a bucket of m pixels is cut into
+// big kernel: the pixel axis is a sequence of 32-pixel steps (per bucket: ceil(M_g / 32)), cut into `split` chunks of `steps` steps each;
+// small kernel: chunks of `chunk` = 32 * steps pixels per bucket
 WgradPlan wgrad_plan(const ConvParams &p, int nseg, const WgradSeg *segs) {
   WgradPlan w{};
-  long M = 0;
-  for (int g = 0; g < nseg; ++g) M += (long)segs[g].B * segs[g].OH * segs[g].OW;
+  long M = 0, total_steps = 0;
+  for (int g = 0; g < nseg; ++g) {
+    const long Mg = (long)segs[g].B * segs[g].OH * segs[g].OW;
+    M += Mg;
+    total_steps += (Mg + 31) / 32;
+  }
   const int K = p.KH * p.KW * p.Cin;
   w.big = p.Cout >= 64 && K >= 128;
   const int tn = w.big && p.Cout >= 128 ? 128 : 64, tk = w.big ? 128 : 64;
@@ -1584,9 +1604,13 @@ WgradPlan wgrad_plan(const ConvParams &p, int nseg, const WgradSeg *segs) {
   if (split > max_split) split = max_split;
   if (split > 256) split = 256;          // (the partial slices are re-read by the reduction)
   if (split < 1) split = 1;
-  w.chunk = (int)(((M + split - 1) / split + 31) / 32 * 32);
-  w.split = 0;
-  for (int g = 0; g < nseg; ++g) w.split += (int)(((long)segs[g].B * segs[g].OH * segs[g].OW + w.chunk - 1) / w.chunk);
+  w.steps = (int)((total_steps + split - 1) / split);
+  w.chunk = w.steps * 32;
+  if (w.big) w.split = (int)((total_steps + w.steps - 1) / w.steps);
+  else {
+    w.split = 0;
+    for (int g = 0; g < nseg; ++g) w.split += (int)(((long)segs[g].B * segs[g].OH * segs[g].OW + w.chunk - 1) / w.chunk);
+  }
   w.nblk = (int)((M + 127) / 128);
   w.part_floats = (size_t)w.split * p.Cout * K;       // (a single slice goes straight to dw unless the launch accumulates)
   w.bias_floats = (size_t)w.nblk * p.Cout;
@@ -1614,32 +1638,38 @@ static int launch_wgrad_segs(ConvParams p, int nseg, const WgradSeg *segs, float
   const WgradPlan w = wgrad_plan(p, nseg, segs);
   const size_t need = (w.part_floats + w.bias_floats) * sizeof(float);
   if (need > ws_bytes || (need && !ws)) return set_error(DF_ERR_WORKSPACE, "wgrad: workspace too small");
-  long M = 0, out_lo = segs[0].out_row0;
+  long M = 0, out_lo = segs[0].out_row0, in_lo = segs[0].in_row0, in_hi = 0;
   for (int g = 0; g < nseg; ++g) {
     const WgradSeg &sg = segs[g];
     if (sg.B <= 0 || sg.H <= 0 || sg.W <= 0 || sg.OH <= 0 || sg.OW <= 0) return set_error(DF_ERR_ARG, "wgrad: empty bucket");
-    if ((size_t)sg.B * sg.H * sg.W * p.in_ld * sizeof(float) >= (1ull << 32) || (size_t)sg.B * sg.OH * sg.OW * p.out_ld * sizeof(float) >= (1ull << 32))
-      return set_error(DF_ERR_ARG, "wgrad: tensor too large (4 GB per operand and bucket)");
     if (sg.out_row0 != out_lo + M) return set_error(DF_ERR_ARG, "wgrad: the buckets' output rows must be contiguous and in order");
+    if (sg.in_row0 < in_lo) return set_error(DF_ERR_ARG, "wgrad: the buckets' input rows must be in order");
+    in_hi = std::max(in_hi, sg.in_row0 + (long)sg.B * sg.H * sg.W);
     M += (long)sg.B * sg.OH * sg.OW;
   }
   if (M >= (1L << 31)) return set_error(DF_ERR_ARG, "wgrad: too many pixels");
+  const size_t in_bytes = (size_t)(in_hi - in_lo) * p.in_ld * sizeof(float), out_bytes = (size_t)M * p.out_ld * sizeof(float);
+  if (in_bytes >= (1ull << 32) || out_bytes >= (1ull << 32)) return set_error(DF_ERR_ARG, "wgrad: tensor too large (4 GB per operand)");
   const bool reduce = w.split > 1 || accumulate;
   float *part = reduce ? static_cast<float *>(ws) : dw;
   float *bpart = static_cast<float *>(ws) + w.part_floats;
   if (w.big) {
     WgTab tab;
     tab.n = nseg;
-    tab.z0[0] = 0;
+    tab.step0[0] = 0;
     for (int g = 0; g < nseg; ++g) {
       const WgradSeg &sg = segs[g];
       const long Mg = (long)sg.B * sg.OH * sg.OW;
-      tab.H[g] = sg.H; tab.W[g] = sg.W; tab.OW[g] = sg.OW; tab.ohw[g] = sg.OH * sg.OW; tab.M[g] = (int)Mg; tab.in_rows[g] = sg.B * sg.H * sg.W;
+      tab.H[g] = sg.H; tab.W[g] = sg.W; tab.OW[g] = sg.OW; tab.ohw[g] = sg.OH * sg.OW; tab.M[g] = (int)Mg;
       make_fdiv((long)sg.OH * sg.OW, tab.ohw_magic[g], tab.ohw_sh[g]);
       make_fdiv(sg.OW, tab.ow_magic[g], tab.ow_sh[g]);
-      tab.in_row0[g] = sg.in_row0; tab.out_row0[g] = sg.out_row0;
-      tab.z0[g + 1] = tab.z0[g] + (int)((Mg + w.chunk - 1) / w.chunk);
+      tab.in_off[g] = (unsigned)((size_t)(sg.in_row0 - in_lo) * p.in_ld * sizeof(float));
+      tab.out_off[g] = (unsigned)((size_t)(sg.out_row0 - out_lo) * p.out_ld * sizeof(float));
+      tab.step0[g + 1] = tab.step0[g] + (int)((Mg + 31) / 32);
     }
+    ConvParams pk = p;                  // operand bases at the first bucket's rows (the buckets' offsets are relative to them)
+    pk.in = p.in + in_lo * p.in_ld;
+    pk.out = p.out + out_lo * p.out_ld;
     constexpr size_t lds128 = (size_t)32 * (132 + 132) * 4, lds64 = (size_t)32 * (68 + 132) * 4;
     auto go = [&](auto tn, size_t lds) {
       constexpr int TN = decltype(tn)::value;
@@ -1650,7 +1680,8 @@ static int launch_wgrad_segs(ConvParams p, int nseg, const WgradSeg *segs, float
         hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_f32_v2_kernel<TN, WGRAD_OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done[dev] = true;
       }
-      hipLaunchKernelGGL((wgrad_f32_v2_kernel<TN, WGRAD_OCC>), dim3((unsigned)(w.tiles * w.split)), dim3(256), lds, st, p, part, w.chunk, w.split, tab);
+      hipLaunchKernelGGL((wgrad_f32_v2_kernel<TN, WGRAD_OCC>), dim3((unsigned)(w.tiles * w.split)), dim3(256), lds, st, pk, part, w.steps, w.split, (unsigned)in_bytes,
+                         (unsigned)out_bytes, tab);
     };
     using std::integral_constant;
     if (p.Cout >= 128) go(integral_constant<int, 128>{}, lds128);
