@@ -95,4 +95,95 @@ __device__ __forceinline__ void knn1_scan(const float *s_ref, int R, const float
   }
 }
 
+// The same scan with the reference points read through the SCALAR cache instead of LDS (the scheme of knn.hip's
+// knn1_dim3_sgpr_kernel), for references stored as [R][3] (x, y, z interleaved: the loss's target points): a chunk of 8 references is 24
+// consecutive floats = three s_load_dwordx8 of a wave-uniform address, requested one chunk ahead; no staging pass, no barrier, no LDS
+// read in the loop.  Same operations in the same order as knn1_scan: the same index, bit for bit.  `tgt` must be wave-uniform.
+template <int QPL>
+__device__ __forceinline__ void knn1_scan_sc(const float *__restrict__ tgt, int R, const float (&qx)[QPL], const float (&qy)[QPL],
+                                             const float (&qz)[QPL], int (&bi)[QPL]) {
+  static_assert(QPL % 2 == 0, "queries are processed as packed pairs");
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int CH = 8;
+  float best[QPL];
+  int bc[QPL];
+  f32x2 qx2[QPL / 2], qy2[QPL / 2], qz2[QPL / 2];
+#pragma unroll
+  for (int j = 0; j < QPL; ++j) { best[j] = __builtin_inff(); bi[j] = 0; bc[j] = 0; }
+#pragma unroll
+  for (int j = 0; j < QPL / 2; ++j) {
+    qx2[j] = f32x2{qx[2 * j], qx[2 * j + 1]};
+    qy2[j] = f32x2{qy[2 * j], qy[2 * j + 1]};
+    qz2[j] = f32x2{qz[2 * j], qz[2 * j + 1]};
+  }
+  const int nchunk = R / CH;
+  float p[CH * 3];
+  if (nchunk > 0) {
+#pragma unroll
+    for (int i = 0; i < CH * 3; ++i) p[i] = tgt[i];
+  }
+  for (int c = 0; c < nchunk; ++c) {
+    float nx[CH * 3];
+    const int cn = c + 1 < nchunk ? c + 1 : c;      // (the last round re-reads its own chunk: no branch in the loop)
+#pragma unroll
+    for (int i = 0; i < CH * 3; ++i) nx[i] = tgt[cn * (CH * 3) + i];      // uniform address, read-only data: scalar loads
+    __builtin_amdgcn_sched_barrier(0);               // the requests go out BEFORE this round's arithmetic
+#pragma unroll
+    for (int j = 0; j < QPL / 2; ++j) {
+      float m0 = __builtin_inff(), m1 = __builtin_inff();
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const f32x2 tx = f32x2{p[3 * i], p[3 * i]} - qx2[j];
+        const f32x2 ty = f32x2{p[3 * i + 1], p[3 * i + 1]} - qy2[j];
+        const f32x2 tz = f32x2{p[3 * i + 2], p[3 * i + 2]} - qz2[j];
+        f32x2 d = tx * tx;
+        d = __builtin_elementwise_fma(ty, ty, d);
+        d = __builtin_elementwise_fma(tz, tz, d);
+        m0 = __builtin_fminf(m0, d.x);
+        m1 = __builtin_fminf(m1, d.y);
+      }
+      const bool lt0 = m0 < best[2 * j], lt1 = m1 < best[2 * j + 1];
+      best[2 * j] = lt0 ? m0 : best[2 * j];
+      bc[2 * j] = lt0 ? c : bc[2 * j];
+      best[2 * j + 1] = lt1 ? m1 : best[2 * j + 1];
+      bc[2 * j + 1] = lt1 ? c : bc[2 * j + 1];
+    }
+#pragma unroll
+    for (int i = 0; i < CH * 3; ++i) p[i] = nx[i];
+  }
+#pragma unroll
+  for (int j = 0; j < QPL; ++j) {
+    float b2 = __builtin_inff();
+    int i2 = 0;
+    const int base = bc[j] * CH;
+    if (nchunk > 0) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {                 // the winning chunk again, per-lane addresses
+        const float tx = tgt[(base + i) * 3] - qx[j], ty = tgt[(base + i) * 3 + 1] - qy[j], tz = tgt[(base + i) * 3 + 2] - qz[j];
+        float d = tx * tx;
+        d = __builtin_fmaf(ty, ty, d);
+        d = __builtin_fmaf(tz, tz, d);
+        const bool lt = d < b2;
+        b2 = lt ? d : b2;
+        i2 = lt ? i : i2;
+      }
+    }
+    bi[j] = b2 < __builtin_inff() ? base + i2 : 0;
+    best[j] = b2;
+  }
+  for (int r = nchunk * CH; r < R; ++r) {            // R % CH tail: plain scan
+    const float x = tgt[r * 3], y = tgt[r * 3 + 1], z = tgt[r * 3 + 2];
+#pragma unroll
+    for (int j = 0; j < QPL; ++j) {
+      const float tx = x - qx[j], ty = y - qy[j], tz = z - qz[j];
+      float d = tx * tx;
+      d = __builtin_fmaf(ty, ty, d);
+      d = __builtin_fmaf(tz, tz, d);
+      const bool lt = d < best[j];
+      best[j] = lt ? d : best[j];
+      bi[j] = lt ? r : bi[j];
+    }
+  }
+}
+
 }  // namespace df

@@ -98,23 +98,21 @@ __global__ __launch_bounds__(LB) void add_dis_kernel(const float *__restrict__ p
 }
 
 // Symmetric objects, many poses (the PoseNet loss: N per-point poses, lib/loss.py:41-47): the N*M transformed model points
-// are the queries of a 1-NN against the M target points.  Same scan as df_knn (knn_core.h: packed v_pk_*_f32 pairs, four
-// queries per lane, chunked arg-min, targets as wave-uniform LDS broadcasts), so `sel` is bit for bit what
-// KNearestNeighbor(1)(target, pred) would return; a workgroup owns `ppb` whole poses (their ppb*M queries in passes of
-// 256*QPL) so that the per-pose distance sums stay inside the workgroup and deterministic.
-constexpr int SYM_QPL = 4;
+// are the queries of a 1-NN against the M target points.  Same scan as df_knn (knn_core.h knn1_scan_sc: packed v_pk_*_f32 pairs, two
+// queries per lane, chunked arg-min, the targets through the SCALAR cache -- three s_load_dwordx8 per chunk of 8, one chunk ahead, no
+// LDS staging, no barrier in the scan), so `sel` is bit for bit what KNearestNeighbor(1)(target, pred) would return; a workgroup owns
+// `ppb` whole poses (their ppb*M queries in passes of 256*QPL) so that the per-pose distance sums stay inside the workgroup and
+// deterministic.
+constexpr int SYM_QPL = 2;      // queries per lane (the scalar-cache scan's best: knn.hip)
 __global__ __launch_bounds__(LB) void add_dis_sym_kernel(const float *__restrict__ pred_r, const float *__restrict__ pred_t,
                                                          const float *__restrict__ points, const float *__restrict__ target,
                                                          const float *__restrict__ model, int P, int M, int ppb,
                                                          float *__restrict__ dis, int *__restrict__ sel_out) {
-  extern __shared__ __attribute__((aligned(16))) float s_tgt[];   // [M][4], then LB*SYM_QPL distances, then ppb totals
+  extern __shared__ __attribute__((aligned(16))) float s_e[];   // LB*SYM_QPL distances, then ppb totals
   __shared__ float s_red[LB];
-  float *s_e = s_tgt + (size_t)M * 4;
   float *s_tot = s_e + LB * SYM_QPL;
   const int tid = threadIdx.x;
   const int p0 = blockIdx.x * ppb, np = min(ppb, P - p0);
-  for (int m = tid; m < M; m += LB)
-    reinterpret_cast<float4 *>(s_tgt)[m] = make_float4(target[m * 3], target[m * 3 + 1], target[m * 3 + 2], 0.f);
   if (tid < ppb) s_tot[tid] = 0.f;
   __syncthreads();
   const int total = np * M;
@@ -136,13 +134,12 @@ __global__ __launch_bounds__(LB) void add_dis_sym_kernel(const float *__restrict
       qy[j] = (x * R.m[3] + y * R.m[4] + z * R.m[5]) + t1;
       qz[j] = (x * R.m[6] + y * R.m[7] + z * R.m[8]) + t2;
     }
-    knn1_scan<SYM_QPL>(s_tgt, M, qx, qy, qz, bi);
+    knn1_scan_sc<SYM_QPL>(target, M, qx, qy, qz, bi);      // the targets through the scalar cache ([M][3] as it comes: knn_core.h)
 #pragma unroll
     for (int j = 0; j < SYM_QPL; ++j) {
       const int i = base + tid + j * LB;
       const bool ok = i < total;
-      const float4 q = reinterpret_cast<const float4 *>(s_tgt)[bi[j]];
-      const float ex = qx[j] - q.x, ey = qy[j] - q.y, ez = qz[j] - q.z;
+      const float ex = qx[j] - target[bi[j] * 3], ey = qy[j] - target[bi[j] * 3 + 1], ez = qz[j] - target[bi[j] * 3 + 2];
       s_e[tid + j * LB] = ok ? sqrtf(ex * ex + ey * ey + ez * ez) : 0.f;
       if (ok && sel_out) sel_out[(size_t)pi[j] * M + mi[j]] = bi[j];      // kept for the backward pass
     }
@@ -442,7 +439,7 @@ extern "C" int df_loss_forward(const float *pred_r, const float *pred_t, const f
   const size_t lds = (size_t)M * 16;
   loss_lds_attrs();
   const int ppb = M >= LB * SYM_QPL ? 1 : std::min(LB, (LB * SYM_QPL) / M);      // (the per-pose totals are kept by tid < ppb <= LB)
-  const size_t lds2 = (size_t)M * 16 + (size_t)LB * SYM_QPL * 4 + (size_t)ppb * 4;
+  const size_t lds2 = (size_t)LB * SYM_QPL * 4 + (size_t)ppb * 4;
   if (symmetric && N >= 2 && lds2 <= 150 * 1024) {
     // the fused transform + shared 1-NN scan (knn_core.h) + distance reduction; ppb whole poses per workgroup fill its
     // 256 lanes x 4 queries

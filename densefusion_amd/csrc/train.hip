@@ -1623,10 +1623,22 @@ int check_flips(Trainer &t, const float *P, long version, hipStream_t st) {
   else
     for (const Trainer::Flip &f : t.flips)
       hipLaunchKernelGGL(flip_kernel, dim3(nblk((long)f.O * f.T * f.I * f.Z, 1024)), dim3(TB), 0, st, P + f.off, t.wflip + f.off, f.O, f.T, f.I, f.KH, f.KW, f.Z);
-  for (const auto &kv : t.wino) {
-    const Trainer::Wino &w = kv.second;
-    launch_wino_weight(P + w.w_off, t.wino_buf + w.fwd, w.O, w.I, st, 4);
-    launch_wino_weight(t.wflip + w.w_off, t.wino_buf + w.bwd, w.I, w.O, st, 4);       // flipped weights: [I][9][O]
+  {   // the F(4x4,3x3)-domain copies, forward (of the packed weights) and data gradient (of the flipped ones: [I][9][O]): one launch per 32
+    WinoWTab tab;
+    tab.n = 0; tab.e0[0] = 0;
+    auto flush = [&]() { launch_wino4_weight_multi(P, t.wflip, t.wino_buf, tab, st); tab.n = 0; tab.e0[0] = 0; };
+    auto push = [&](int O, int C, int from_b, long src, long dst) {
+      if (tab.n == WINO_WMAX) flush();
+      const int g = tab.n++;
+      tab.O[g] = O; tab.C[g] = C; tab.from_b[g] = from_b; tab.src_off[g] = src; tab.dst_off[g] = dst;
+      tab.e0[g + 1] = tab.e0[g] + (long)O * C;
+    };
+    for (const auto &kv : t.wino) {
+      const Trainer::Wino &w = kv.second;
+      push(w.O, w.I, 0, (long)w.w_off, (long)w.fwd);
+      push(w.I, w.O, 1, (long)w.w_off, (long)w.bwd);
+    }
+    flush();
   }
   t.flip_version = version;
   t.flip_src = P;

@@ -13,6 +13,11 @@ WinoGeom wino_geom(int B, int H, int W, int dil, int m = 2);
 // layer-geometry-only decision (never batch dependent): 0 = direct implicit GEMM, 2 / 4 = the transform-domain product with that tile
 int wino_route(int H, int W, int dil, int Cin, int Cout);
 void launch_wino_weight(const float *w_packed /*[O][3][3][C]*/, float *U /*[(m+2)^2][O][C]*/, int O, int C, hipStream_t st, int m = 2);
+// F(4x4,3x3) weight transforms of up to WINO_WMAX tensors in one launch: segment g = O[g] x C[g] packed 3x3 kernels at
+// (from_b[g] ? src_b : src_a) + src_off[g] -> dst + dst_off[g]; e0 = prefix of O * C
+constexpr int WINO_WMAX = 32;
+struct WinoWTab { int n; int O[WINO_WMAX], C[WINO_WMAX], from_b[WINO_WMAX]; long src_off[WINO_WMAX], dst_off[WINO_WMAX], e0[WINO_WMAX + 1]; };
+void launch_wino4_weight_multi(const float *src_a, const float *src_b, float *dst, const WinoWTab &tab, hipStream_t st);
 // Ttot / t0: the tiles of this call are rows [t0, t0 + T) of planes that hold Ttot tiles each (several crop-size buckets share
 // one Winograd-domain GEMM); Ttot = 0 means the call owns the planes (Ttot = T, t0 = 0)
 void launch_wino_input(const float *x, int in_ld, int in_coff, float *V /*[(m+2)^2][Ttot][C]*/, int B, int H, int W, int C, int dil,

@@ -195,6 +195,38 @@ __global__ __launch_bounds__(WB) void wino4_weight_kernel(const float *__restric
   }
 }
 
+// the same for a list of weight tensors in one launch (the trainer re-derives 22 of them after every optimizer step): segment g =
+// O[g] x C[g] kernels at src + src_off[g] -> dst + dst_off[g]; a thread finds its segment by a scan of the element prefix
+__global__ __launch_bounds__(WB) void wino4_weight_multi_kernel(const float *__restrict__ src_a, const float *__restrict__ src_b, float *__restrict__ dst,
+                                                                const WinoWTab tab) {
+  const double G[6][3] = {{1, 0, 0}, {1. / 3, 1. / 3, 1. / 3}, {-1. / 3, 1. / 3, -1. / 3}, {-16. / 15, -8. / 15, -4. / 15},
+                          {1. / 15, -2. / 15, 4. / 15}, {0, 0, 1}};
+  const long n = tab.e0[tab.n];
+  for (long e0 = (long)blockIdx.x * WB + threadIdx.x; e0 < n; e0 += (long)gridDim.x * WB) {
+    int sgi = 0;
+    while (sgi + 1 < tab.n && e0 >= tab.e0[sgi + 1]) ++sgi;
+    const long e = e0 - tab.e0[sgi];
+    const int O = tab.O[sgi], C = tab.C[sgi];
+    const float *w = (tab.from_b[sgi] ? src_b : src_a) + tab.src_off[sgi];
+    float *U = dst + tab.dst_off[sgi];
+    const int o = (int)(e / C), c = (int)(e % C);
+    double g[3][3], t[6][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) g[i][j] = (double)w[((size_t)o * 9 + i * 3 + j) * C + c];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0][j] + G[i][1] * g[1][j] + G[i][2] * g[2][j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        U[((size_t)(i * 6 + j) * O + o) * C + c] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+  }
+}
+
 // V[z = i*6+j][t][c] = (B^T d B)[i][j]; one thread per (tile, 4 channels): 36 vector loads in flight per thread
 __device__ __forceinline__ void wino4_input_body(const float *__restrict__ x, int in_ld, int in_coff, float *__restrict__ V, int H, int W, int C, int d,
                                                  int TH, int TW, long T, long Ttot, long t0, long e_begin, long e_step) {
@@ -349,6 +381,11 @@ int wino_route(int H, int W, int dil, int Cin, int Cout) {
 void launch_wino_weight(const float *w_packed, float *U, int O, int C, hipStream_t st, int m) {
   if (m == 4) hipLaunchKernelGGL(wino4_weight_kernel, dim3(blocks_for((long)O * C)), dim3(WB), 0, st, w_packed, U, O, C);
   else hipLaunchKernelGGL(wino_weight_kernel, dim3(blocks_for((long)O * C)), dim3(WB), 0, st, w_packed, U, O, C);
+}
+
+void launch_wino4_weight_multi(const float *src_a, const float *src_b, float *dst, const WinoWTab &tab, hipStream_t st) {
+  if (tab.n <= 0) return;
+  hipLaunchKernelGGL(wino4_weight_multi_kernel, dim3(blocks_for(tab.e0[tab.n])), dim3(WB), 0, st, src_a, src_b, dst, tab);
 }
 
 void launch_wino_input(const float *x, int in_ld, int in_coff, float *V, int B, int H, int W, int C, int dil, hipStream_t st, long Ttot,
