@@ -93,7 +93,7 @@ def ply_vtx(path):
     return np.array(pts)
 
 
-def get_item(rgb, depth, label, mode, meta, model_pts_mm, keep_rows, num, seed):
+def get_item(rgb, depth, label, mode, meta, model_pts_mm, keep_rows, num, seed, choose_given=None):
     """One frame (dataset.py:90-195).  rgb [480,640,3+] u8, depth [480,640] u16, label: 'eval' [480,640] u8,
     otherwise the [480,640,3] mask image.  meta: the gt.yml entry.  -> (cloud, choose, img, target, model_points)
     or None when no mask pixel lies in the crop (:135-137)."""
@@ -114,7 +114,9 @@ def get_item(rgb, depth, label, mode, meta, model_pts_mm, keep_rows, num, seed):
     choose = mask[rmin:rmax, cmin:cmax].flatten().nonzero()[0]
     if len(choose) == 0:
         return None
-    if len(choose) > num:
+    if choose_given is not None:           # the pixel subset as an input (the reference's own np.random.shuffle draw, tests/golden)
+        choose = np.asarray(choose_given).reshape(-1).astype(np.int64)
+    elif len(choose) > num:
         keys = mix32(seed, choose)
         order = np.lexsort((choose, keys))[:num]
         choose = np.sort(choose[order])

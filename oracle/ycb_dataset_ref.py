@@ -56,7 +56,7 @@ def get_bbox(label):
     return int(rmin), int(rmax), int(cmin), int(cmax)
 
 
-def get_item(rgb, depth, label, meta, seq_no, idx, cld, keep_rows, num_pt, seed):
+def get_item(rgb, depth, label, meta, seq_no, idx, cld, keep_rows, num_pt, seed, choose_given=None):
     """One real frame with object slot `idx` (dataset.py:90-217) -> cloud, choose, img, target, model_points, box."""
     cam = (323.7872, 279.6921, 1077.836, 1078.189) if seq_no >= 60 else (312.9869, 241.3109, 1066.778, 1067.487)
     cam_cx, cam_cy, cam_fx, cam_fy = (np.float32(v) for v in cam)
@@ -69,7 +69,9 @@ def get_item(rgb, depth, label, meta, seq_no, idx, cld, keep_rows, num_pt, seed)
     target_r = meta["poses"][:, :, idx][:, 0:3]
     target_t = np.array([meta["poses"][:, :, idx][:, 3:4].flatten()])
     choose = mask[rmin:rmax, cmin:cmax].flatten().nonzero()[0]
-    if len(choose) > num_pt:
+    if choose_given is not None:           # the pixel subset as an input (the reference's own np.random.shuffle draw, tests/golden)
+        choose = np.asarray(choose_given).reshape(-1).astype(np.int64)
+    elif len(choose) > num_pt:
         keys = mix32(seed, choose)
         order = np.lexsort((choose, keys))[:num_pt]
         choose = np.sort(choose[order])

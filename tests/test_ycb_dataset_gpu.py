@@ -13,68 +13,7 @@ from densefusion_amd import synth
 from oracle import ycb_dataset_ref
 
 pytestmark = pytest.mark.gpu
-CLASSES = ["002_master_chef_can", "003_cracker_box", "004_sugar_box", "005_tomato_soup_can"]
-
-
-def make_tree(root, cfg, rng):
-    os.makedirs(cfg)
-    with open(f"{cfg}/classes.txt", "w") as f:
-        f.write("\n".join(CLASSES) + "\n")
-    for c in CLASSES:
-        os.makedirs(f"{root}/models/{c}")
-        np.savetxt(f"{root}/models/{c}/points.xyz", (rng.random((2700, 3)) - 0.5) * 0.2, fmt="%.6f")
-    names = []
-    for seq, frames in (("0001", 3), ("0060", 3)):
-        os.makedirs(f"{root}/data/{seq}")
-        for fr in range(frames):
-            name = f"data/{seq}/{fr + 1:06d}"
-            names.append(name)
-            rgb = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
-            depth = rng.integers(4000, 15000, (480, 640)).astype(np.uint16)
-            depth[rng.random((480, 640)) < 0.08] = 0
-            label = np.zeros((480, 640), dtype=np.uint8)
-            present = [1, 3, 4] if fr % 2 == 0 else [2, 4]
-            for k, c in enumerate(present):
-                h, w = int(rng.integers(40, 200)), int(rng.integers(40, 260))
-                r0, c0 = int(rng.integers(0, 480 - h)), int(rng.integers(0, 640 - w))
-                label[r0:r0 + h, c0:c0 + w][rng.random((h, w)) < 0.7] = c
-            if fr == 1:
-                label[label == 4] = 0
-                label[5:9, 5:12] = 4                                  # object 4: 28 pixels only -> never selected (minimum 50)
-            poses = np.stack([np.concatenate([synth.quat_to_rot(synth.random_unit_quaternion(rng)), rng.normal(size=(3, 1)) * 0.2 + [[0], [0], [1.0]]], axis=1)
-                              for _ in present], axis=2)
-            Image.fromarray(rgb).save(f"{root}/{name}-color.png")
-            Image.fromarray(depth).save(f"{root}/{name}-depth.png")
-            Image.fromarray(label).save(f"{root}/{name}-label.png")
-            scio.savemat(f"{root}/{name}-meta.mat", {"cls_indexes": np.array(present, dtype=np.uint8)[:, None], "poses": poses,
-                                                     "factor_depth": np.array([[10000]], dtype=np.uint16)})
-    os.makedirs(f"{root}/data_syn")
-    syn = []
-    for fr in range(2):                                           # synthetic frames: RGBA renders on black, three objects each
-        name = f"data_syn/{fr:06d}"
-        syn.append(name)
-        label = np.zeros((480, 640), dtype=np.uint8)
-        present = [1, 2, 3]
-        for c in present:
-            h, w = int(rng.integers(150, 260)), int(rng.integers(200, 330))
-            r0, c0 = int(rng.integers(0, 480 - h)), int(rng.integers(0, 640 - w))
-            label[r0:r0 + h, c0:c0 + w][rng.random((h, w)) < 0.8] = c
-        rgba = rng.integers(0, 256, (480, 640, 4), dtype=np.uint8)
-        rgba[label == 0] = 0
-        rgba[..., 3] = np.where(label > 0, 255, 0)
-        depth = rng.integers(4000, 15000, (480, 640)).astype(np.uint16)
-        poses = np.stack([np.concatenate([synth.quat_to_rot(synth.random_unit_quaternion(rng)), rng.normal(size=(3, 1)) * 0.2 + [[0], [0], [1.0]]], axis=1)
-                          for _ in present], axis=2)
-        Image.fromarray(rgba).save(f"{root}/{name}-color.png")
-        Image.fromarray(depth).save(f"{root}/{name}-depth.png")
-        Image.fromarray(label).save(f"{root}/{name}-label.png")
-        scio.savemat(f"{root}/{name}-meta.mat", {"cls_indexes": np.array(present, dtype=np.uint8)[:, None], "poses": poses,
-                                                 "factor_depth": np.array([[10000]], dtype=np.uint16)})
-    with open(f"{cfg}/test_data_list.txt", "w") as f:
-        f.write("\n".join(names) + "\n")
-    with open(f"{cfg}/train_data_list.txt", "w") as f:
-        f.write("\n".join(names[:4] + syn) + "\n")
-    return names
+from fabricate import CLASSES, make_ycb_tree as make_tree  # noqa: E402,F401
 
 
 @pytest.mark.parametrize("refine", [False, True])
