@@ -504,6 +504,28 @@ def bench_train(device):
     out["frames_per_s"]["1_per_pass_mixed_crop_sizes"] = round(6 * acc / (time.perf_counter() - t0), 1)
     out["mixed_crop_sizes"] = [list(CROPS[j % len(CROPS)]) for j in range(acc)]
 
+    # this fork's own default accumulation window (tools/train.py:34 of the reference: --batch_size 32): 32 frames of mixed crop sizes as one pass
+    big = []
+    for j in range(32):
+        Hm, Wm = CROPS[j % len(CROPS)]
+        o = synth.make_object(800 + j, Hm, Wm, N, K, M)
+        o["obj"][0] = [12, 3, 15, 7][j % 4]
+        big.append(dict(img=torch.from_numpy(o["img"]).to(device), cloud=torch.from_numpy(o["cloud"]).to(device), choose=torch.from_numpy(o["choose"]).to(device),
+                        obj=torch.from_numpy(o["obj"]).to(device), target=torch.from_numpy(o["target"]).to(device),
+                        model_points=torch.from_numpy(o["model_points"]).to(device), symmetric=int(o["obj"][0]) in sym_list))
+
+    def window32():
+        tr.step_posenet_window(big, 0.015, dropout=True)
+        train_utils.allreduce_gradients(tr); opt.step(grad_scale=1.0 / 32); tr.zero_grad()
+
+    window32(); window32()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        window32()
+    torch.cuda.synchronize()
+    out["frames_per_s"]["window_of_32_mixed_crop_sizes"] = round(3 * 32 / (time.perf_counter() - t0), 1)
+
     # roofline of the native step on EXECUTED FLOPs (df_trainer_profile: HIP events around every MFMA launch of the step on its stream;
     # FLOPs = 2 M N K of the shapes really launched -- low-resolution up-convolutions, folded head layer 1, chosen-pixel up_3,
     # F(4x4,3x3)-domain products -- not the reference graph's)
@@ -517,10 +539,12 @@ def bench_train(device):
         return {k: (ms / reps, fl / reps, n // reps) for k, (ms, fl, n) in prof.items()}
 
     roof = {}
-    for name, fn, fps_key in (("8_per_pass", lambda: window(acc, False), "8_per_pass"), ("mixed_crop_sizes_one_pass", mixed_one_pass, "1_per_pass_mixed_crop_sizes")):
+    for name, fn, fps_key, nfr in (("8_per_pass", lambda: window(acc, False), "8_per_pass", acc),
+                                   ("mixed_crop_sizes_one_pass", mixed_one_pass, "1_per_pass_mixed_crop_sizes", acc),
+                                   ("window_of_32_mixed_crop_sizes", window32, "window_of_32_mixed_crop_sizes", 32)):
         prof = profiled(fn)
         ms_all = sum(v[0] for v in prof.values()); fl_all = sum(v[1] for v in prof.values())
-        wall_ms = acc / out["frames_per_s"][fps_key] * 1e3
+        wall_ms = nfr / out["frames_per_s"][fps_key] * 1e3
         roof[name] = {"kernel": "igemm_f32_v4 / v2 (forward, data gradient) + wgrad_f32_v2 (weight gradient), all MFMA launches of one optimizer window",
                       "bound": "mfma", "unit": "TFLOP/s", "peak": FP32_PEAK_TFLOPS,
                       "achieved": round(fl_all / ms_all / 1e9, 2), "frac": round(fl_all / ms_all / 1e9 / FP32_PEAK_TFLOPS, 4),

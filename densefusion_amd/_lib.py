@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfusion_hip.so")
+# DF_DEV_LIB=1 (tests that compare kernel variants): the -DDF_DEV build, the only one that reads development switches from the environment
+LIB_PATH = os.path.join(_HERE, "libdfusion_hip_dev.so" if os.environ.get("DF_DEV_LIB") else "libdfusion_hip.so")
 _lib = None
 
 _vp, _i, _i64, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t

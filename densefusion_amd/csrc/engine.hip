@@ -392,14 +392,14 @@ static ConvParams point_gemm(const float *in, int in_ld, int in_coff, int cin, c
 
 // dev switch (A/B runs): DF_POINT_UNFUSED = the K = 3 / 32 / 64 per-point layers as separate launches (round 2) instead of pointfeat.hip
 static bool point_fused() {
-  static const bool on = getenv("DF_POINT_UNFUSED") == nullptr;
+  static const bool on = df::dev_getenv("DF_POINT_UNFUSED") == nullptr;
   return on;
 }
 
 // dev switches (A/B runs): DF_NO_WINOGRAD = direct convolutions only, DF_WINOGRAD_TILE = 2 keeps F(2x2,3x3) where a Winograd route pays
 static int wino_route_for(int H, int W, int dil, int ci, int co) {
-  static const bool off = getenv("DF_NO_WINOGRAD") != nullptr;
-  static const int force = getenv("DF_WINOGRAD_TILE") ? atoi(getenv("DF_WINOGRAD_TILE")) : 0;
+  static const bool off = df::dev_getenv("DF_NO_WINOGRAD") != nullptr;
+  static const int force = df::dev_getenv("DF_WINOGRAD_TILE") ? atoi(df::dev_getenv("DF_WINOGRAD_TILE")) : 0;
   if (off) return 0;
   const int r = wino_route(H, W, dil, ci, co);
   return (r && force == 2) ? 2 : r;
@@ -502,7 +502,7 @@ static float *cnn_forward(Ctx &c, const std::vector<Grp> &gs, Level &half_lv) {
       std::vector<long> trow;
       for (int i : ws[r]) { tB.push_back(gs[i].B); tH.push_back(li.h[i]); tW.push_back(li.w[i]); trow.push_back(li.off[i]); }
       const int nw = (int)ws[r].size();
-      static const bool per_bucket = getenv("DF_WINO_PER_BUCKET") != nullptr;       // dev switch: one transform launch per bucket (A/B)
+      static const bool per_bucket = df::dev_getenv("DF_WINO_PER_BUCKET") != nullptr;       // dev switch: one transform launch per bucket (A/B)
       if (m == 4 && !per_bucket) {
         if (c.live()) launch_wino4_input_multi(in, ci, V, nw, tB.data(), tH.data(), tW.data(), trow.data(), t0.data(), ci, dil, T, c.st);
       } else {
@@ -877,7 +877,7 @@ extern "C" int df_net_profile_read(df_net *h, double *gemm_ms, double *gemm_flop
   if (!h) return set_error(DF_ERR_ARG, "profile_read: null handle");
   Net *n = as_net(h);
   double ms = 0, fl = 0, by = 0, us = 0;
-  static const bool verbose = getenv("DF_PROFILE_VERBOSE") != nullptr;
+  static const bool verbose = df::dev_getenv("DF_PROFILE_VERBOSE") != nullptr;
   for (size_t i = 0; i + 1 < n->ev_used; i += 2) {
     float t = 0;
     if (hipEventElapsedTime(&t, n->ev[i], n->ev[i + 1]) != hipSuccess) return set_error(DF_ERR_LAUNCH, "profile_read: events not complete");

@@ -1332,7 +1332,7 @@ struct TileCfg { int bm, bn, wmv; };     // workgroup tile and waves along M
 // Launches the product kernel (v4) takes; the rest -- input dilation (the data gradient of a strided convolution), operands of
 // 4 GB or more per z slice (a buffer descriptor's reach), channel offsets / strides that are not multiples of 4 -- go to v1.
 bool takes_v4(const ConvParams &p) {
-  static const bool force_v1 = getenv("DF_IGEMM_V1") != nullptr;   // dev switch: A/B against the un-pipelined kernel; read once
+  static const bool force_v1 = df::dev_getenv("DF_IGEMM_V1") != nullptr;   // dev switch: A/B against the un-pipelined kernel; read once
   const size_t in_bytes = (size_t)p.B * p.H * p.W * p.in_ld * sizeof(float);      // per z slice
   const size_t w_bytes = (size_t)p.Cout * p.KH * p.KW * p.Cin * sizeof(float);
   return !force_v1 && p.up == 1 && p.H + p.pad < 32768 && p.W + p.pad < 32768 && p.out_ld < (1 << 21) && p.res_ld < (1 << 21) && in_bytes < (1ull << 32) && w_bytes < (1ull << 32) && p.Cout % 4 == 0 && p.out_ld % 4 == 0 &&
@@ -1351,7 +1351,7 @@ TileCfg pick_cfg(const ConvParams &p) {
   // a batched call stays bit-identical to solo calls) by always using the 128x128 tile for it.
   if (p.colsum || !p.out) return {128, 128, 2};     // (!p.out: the same launch while its partial buffer is being sized)
   const bool v4 = takes_v4(p);                      // v1 has the two square tiles only
-  static const char *const tile_env = getenv("DF_IGEMM_TILE");      // dev switch for A/B runs; read once
+  static const char *const tile_env = df::dev_getenv("DF_IGEMM_TILE");      // dev switch for A/B runs; read once
   if (tile_env) {
     if (tile_env[0] == 'a') return {128, 128, 2};
     if (tile_env[0] == 'b' && v4) return {128, 64, 2};
@@ -1416,7 +1416,7 @@ int launch_conv(const ConvParams &p, hipStream_t st, int *splitk_used) {
   {
     const size_t slice = (size_t)c.bn * p.KH * p.KW * p.Cin * sizeof(float);       // weights of one column tile
     const long tn = (p.Cout + c.bn - 1) / c.bn;
-    static const long budget = getenv("DF_IGEMM_WGROUP_KB") ? atol(getenv("DF_IGEMM_WGROUP_KB")) * 1024L : 3L << 20;
+    static const long budget = df::dev_getenv("DF_IGEMM_WGROUP_KB") ? atol(df::dev_getenv("DF_IGEMM_WGROUP_KB")) * 1024L : 3L << 20;
     if (budget > 0 && (size_t)tn * slice > (size_t)budget) pl.ngroup = (int)std::max<long>(1, budget / (long)slice);
   }
   set_tile_decode();
@@ -1440,7 +1440,7 @@ int launch_conv(const ConvParams &p, hipStream_t st, int *splitk_used) {
   }
   constexpr size_t ROW = 36 * sizeof(float);      // one padded k-tile row (BKT = 32)
   // workgroups per CU of the v4 kernel: 4 / 5 / 6 (the register budget amdgpu_waves_per_eu leaves each: 128 / 102 / 85 VGPRs + AGPRs)
-  static const bool no_pure = getenv("DF_IGEMM_NOPURE") != nullptr;      // dev switch: the general loader for every launch; read once
+  static const bool no_pure = df::dev_getenv("DF_IGEMM_NOPURE") != nullptr;      // dev switch: the general loader for every launch; read once
   const bool v4 = takes_v4(p);
   const int taps = p.KH * p.KW;
   const size_t shifted = ((size_t)p.B * p.H * p.W + (size_t)p.pad * p.W + p.pad) * p.in_ld * sizeof(float);
@@ -1466,7 +1466,7 @@ int launch_conv(const ConvParams &p, hipStream_t st, int *splitk_used) {
     grid.z = S;
   }
   // grids under two workgroups per CU: the software-pipelined kernel (training, 1 / 8 frames per pass: 142 -> 154 / 670 -> 696 frames/s)
-  static const long lowocc = getenv("DF_IGEMM_LOWOCC") ? atol(getenv("DF_IGEMM_LOWOCC")) : 512;    // dev switch; read once
+  static const long lowocc = df::dev_getenv("DF_IGEMM_LOWOCC") ? atol(df::dev_getenv("DF_IGEMM_LOWOCC")) : 512;    // dev switch; read once
   if (v4 && S == 1 && tiles * p.zcount < lowocc && c.bn == c.bm) {
     if (c.bm == 128)
       hipLaunchKernelGGL((igemm_f32_v2_kernel<128, 128, 2, 2, 32>), grid, dim3(256), (size_t)2 * 256 * 36 * sizeof(float), st, pl);

@@ -18,6 +18,7 @@ namespace {
 
 constexpr int KNN_BLOCK = 256;
 
+#ifdef DF_DEV      // the LDS-staged round-2 kernel: kept for A/B runs of the dev build only (DF_KNN_VARIANT)
 // dim == 3, k == 1.  grid = (ceil(Q / (KNN_BLOCK*QPL)), batch)
 template <int QPL>
 __global__ __launch_bounds__(KNN_BLOCK) void knn1_dim3_kernel(const float *__restrict__ ref, int R,
@@ -56,6 +57,8 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn1_dim3_kernel(const float *__res
     if (q < Q) ind[q] = (int64_t)bi[j] + 1;
   }
 }
+
+#endif
 
 // The same scan with the reference points read through the SCALAR cache instead of LDS (s_load_dwordx8 of eight x, eight y, eight z:
 // the planar [3][R] layout of the reference's API is exactly what a scalar load wants): no staging pass, no barrier, no LDS reads
@@ -308,7 +311,8 @@ int launch_knn(const float *ref, const float *query, int64_t *idx, int batch, in
     // default: reference points through the scalar cache, 2 queries per lane (measured on 500 x 500 000 / 64 x 500 x 1 000 000:
     // 41.8 us / 3.46 ms against 48.3 us / 3.86 ms for the LDS-staged kernel; 4 queries per lane 45.8 us / 3.53 ms).
     // DF_KNN_VARIANT (dev switch, A/B runs): 2 = scalar cache, 4 per lane; 3 / 4 = LDS-staged, 4 / 2 per lane (R <= 4096)
-    static const int variant = getenv("DF_KNN_VARIANT") ? atoi(getenv("DF_KNN_VARIANT")) : 0;
+#ifdef DF_DEV
+    static const int variant = df::dev_getenv("DF_KNN_VARIANT") ? atoi(df::dev_getenv("DF_KNN_VARIANT")) : 0;
     const bool lds_ok = (size_t)R * 16 <= 64 * 1024;
     if (variant == 3 && lds_ok) {
       hipLaunchKernelGGL(knn1_dim3_kernel<4>, dim3(df::cdiv(Q, KNN_BLOCK * 4), batch), dim3(KNN_BLOCK), (size_t)R * 16, st, ref, R, query, Q, idx);
@@ -316,7 +320,11 @@ int launch_knn(const float *ref, const float *query, int64_t *idx, int batch, in
       hipLaunchKernelGGL(knn1_dim3_kernel<2>, dim3(df::cdiv(Q, KNN_BLOCK * 2), batch), dim3(KNN_BLOCK), (size_t)R * 16, st, ref, R, query, Q, idx);
     } else if (variant == 2) {
       hipLaunchKernelGGL((knn1_dim3_sgpr_kernel<4, 1>), dim3(df::cdiv(Q, KNN_BLOCK * 4), batch), dim3(KNN_BLOCK), 0, st, ref, R, query, Q, idx);
-    } else {
+    } else
+#else
+    constexpr int variant = 0;
+#endif
+    {
       // waves the launch would give every SIMD with one wave per 128 queries; below ~2 rounds of 8 the references are split too
       const double wps = (double)Q * batch / 128.0 / 1024.0;
       const int split = variant == 5 ? 1 : variant == 6 ? 2 : variant == 7 ? 4 : (wps < 6.0 && R >= 64 ? (wps < 3.0 ? 4 : 2) : 1);

@@ -1282,7 +1282,7 @@ struct Step {
 #ifdef DF_DEV
   // dev build, DF_TRAIN_DEBUG=1: synchronise after every phase and name it on stderr (localises a faulting launch)
   void dbg(const char *what, const std::string &extra = std::string()) {
-    static const bool on = getenv("DF_TRAIN_DEBUG") != nullptr;
+    static const bool on = df::dev_getenv("DF_TRAIN_DEBUG") != nullptr;
     if (!on || dry) return;
     const hipError_t e = hipStreamSynchronize(st);
     fprintf(stderr, "[df-train] %s %s: %s\n", what, extra.c_str(), e == hipSuccess ? "ok" : hipGetErrorString(e));

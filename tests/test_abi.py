@@ -60,3 +60,13 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dp, fn)).read()
                 assert "oracle" not in txt.replace("# oracle", "").replace("oracle is", "").replace(
                     "the oracle", "").replace("oracle/", ""), f"{fn} references the oracle package"
+
+
+def test_the_shipped_library_reads_no_environment(built_lib):
+    """Development switches live in the -DDF_DEV build only (libdfusion_hip_dev.so, loaded by the variant-comparison tests): the product
+    library does not even import getenv."""
+    import subprocess
+    und = subprocess.run(["nm", "-D", "--undefined-only", built_lib], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    dev = built_lib.replace("libdfusion_hip.so", "libdfusion_hip_dev.so")
+    assert os.path.exists(dev) and "getenv" in subprocess.run(["nm", "-D", "--undefined-only", dev], capture_output=True, text=True, check=True).stdout

@@ -263,7 +263,7 @@ def test_specialised_loaders_are_bit_identical_to_the_general_one(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = []
-    for tag, env in (("special", {}), ("general", {"DF_IGEMM_NOPURE": "1"})):
+    for tag, env in (("special", {}), ("general", {"DF_DEV_LIB": "1", "DF_IGEMM_NOPURE": "1"})):
         f = str(tmp_path / f"{tag}.pt")
         e = dict(os.environ)
         e.update(env)

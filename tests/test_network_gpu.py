@@ -336,7 +336,7 @@ def test_fused_point_layers_are_bit_identical_to_the_layer_by_layer_launches(tmp
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = []
-    for tag, env in (("fused", {}), ("unfused", {"DF_POINT_UNFUSED": "1"})):
+    for tag, env in (("fused", {}), ("unfused", {"DF_DEV_LIB": "1", "DF_POINT_UNFUSED": "1"})):
         f = str(tmp_path / f"{tag}.pt")
         e = dict(os.environ)
         e.update(env)

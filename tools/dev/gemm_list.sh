@@ -1,7 +1,7 @@
 #!/bin/bash
 # Dev tool (GPU box): per-launch GEMM table of one serial bench step -> gpurun_out/<tag>_gemm_list.txt
 TAG=${1:-r02}; shift || true
-DF_PROFILE_VERBOSE=1 timeout -k 10 300 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-knn --no-graph "$@" 2> gpurun_out/${TAG}_gemm_raw.txt > gpurun_out/${TAG}_gemm_bench.json
+DF_DEV_LIB=1 DF_PROFILE_VERBOSE=1 timeout -k 10 300 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-knn --no-graph "$@" 2> gpurun_out/${TAG}_gemm_raw.txt > gpurun_out/${TAG}_gemm_bench.json
 python3 - <<PY
 import re,collections
 rows=[]

@@ -1,6 +1,7 @@
 """Dev tool: per-GEMM-launch time / TFLOP/s of one batched bucket (DF_PROFILE_VERBOSE dump)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["DF_DEV_LIB"] = "1"          # the development build: the only one that reads switches
 os.environ["DF_PROFILE_VERBOSE"] = "1"
 import torch
 import bench
