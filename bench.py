@@ -224,7 +224,7 @@ def profile_gemm(pe, groups, steps):
     return tot[0], tot[1], tot[2], tot[3], tot_n
 
 
-TRAFFIC_FILE = "r03_igemm_traffic.json"
+TRAFFIC_FILE = "r04_igemm_traffic.json"
 
 
 def measured_traffic(groups, per_bucket):
