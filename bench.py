@@ -526,6 +526,45 @@ def bench_train(device):
     torch.cuda.synchronize()
     out["frames_per_s"]["window_of_32_mixed_crop_sizes"] = round(3 * 32 / (time.perf_counter() - t0), 1)
 
+    # refiner phase (tools/train.py:139-159 of the reference; batch_size / iteration = 16 frames per optimizer step at this fork's defaults): the
+    # frozen estimator over the window's mixed crop sizes in one multi-bucket forward, Loss(refine=True) per frame, then `iteration` = 2 native
+    # refiner steps over all 16 frames -- what tools/train.py --refine_start runs per window
+    from densefusion_amd.lib.network import PoseNet as _PoseNet
+    est = _PoseNet(N, K); est.load_state_dict(sd); est = est.to(device).eval()
+    rtr = NativeTrainer("refiner", N, K, device)
+    rtr.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.refiner_spec(K), WSEED + 1000).items()})
+    ropt = train_utils.FlatAdam(rtr, lr=1e-4)
+    crit = Loss(M, sym_list)
+    rframes = big[:16]
+    by_size = {}
+    for f in rframes:
+        by_size.setdefault(tuple(f["img"].shape[-2:]), []).append(f)
+    rorder = [f for g in by_size.values() for f in g]
+
+    def refine_window():
+        stack = lambda k: torch.stack([f[k] for f in rorder])
+        obj, mp = stack("obj"), stack("model_points")
+        with torch.no_grad():
+            pr, pt, pc, emb = est.forward_multi([torch.stack([f["img"] for f in g]) for g in by_size.values()], stack("cloud"), stack("choose"), obj)
+            npts, ntg = [], []
+            for b, f in enumerate(rorder):
+                _, _, a, t = crit(pr[b:b + 1], pt[b:b + 1], pc[b:b + 1], f["target"][None], f["model_points"][None], f["obj"][None], f["cloud"][None], 0.015, True)
+                npts.append(a); ntg.append(t)
+            npts, ntg = torch.cat(npts), torch.cat(ntg)
+        for _ in range(2):
+            o = rtr.step_refiner(npts, emb, obj, ntg, mp, [f["symmetric"] for f in rorder])
+            npts, ntg = o["new_points"], o["new_target"]
+        train_utils.allreduce_gradients(rtr); ropt.step(grad_scale=1.0 / len(rorder)); rtr.zero_grad()
+
+    refine_window(); refine_window()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(6):
+        refine_window()
+    torch.cuda.synchronize()
+    out["frames_per_s"]["refiner_phase_window_of_16_mixed_crop_sizes"] = round(6 * len(rorder) / (time.perf_counter() - t0), 1)
+    del est, rtr, ropt
+
     # roofline of the native step on EXECUTED FLOPs (df_trainer_profile: HIP events around every MFMA launch of the step on its stream;
     # FLOPs = 2 M N K of the shapes really launched -- low-resolution up-convolutions, folded head layer 1, chosen-pixel up_3,
     # F(4x4,3x3)-domain products -- not the reference graph's)

@@ -40,6 +40,8 @@ SIGNATURES = {
     "df_net_load_param": (_i, [_vp, ctypes.c_char_p, _vp, _i64]),
     "df_posenet_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "df_posenet_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "df_posenet_multi_workspace_bytes": (_sz, [_vp, _i, _vp, _vp, _vp]),
+    "df_posenet_forward_multi": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "df_refiner_workspace_bytes": (_sz, [_vp, _i]),
     "df_refiner_forward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "df_estimate_workspace_bytes": (_sz, [_vp, _vp, _i, _i, _i]),

@@ -975,6 +975,35 @@ extern "C" int df_posenet_forward(df_net *h, int B, int H, int W, const float *i
   return finish(c, "posenet_forward");
 }
 
+// the same forward over buckets of different crop sizes in ONE pass (objects concatenated in bucket order): what the refiner phase of
+// tools/train.py:139-145 needs of its frozen estimator for a whole accumulation window
+extern "C" size_t df_posenet_multi_workspace_bytes(const df_net *h, int nb, const int *B, const int *H, const int *W) {
+  std::vector<Grp> gs;
+  if (!h || as_net(h)->kind != 0 || make_groups(as_net(h), nb, B, H, W, nullptr, gs) != DF_OK) return 0;
+  Ctx c{const_cast<Net *>(as_net(h)), nullptr, true, nullptr};
+  PoseNetOut o{};
+  posenet_forward(c, gs, nullptr, nullptr, nullptr, o);
+  return c.peak;
+}
+
+extern "C" int df_posenet_forward_multi(df_net *h, int nb, const int *B, const int *H, const int *W, const float *const *img, const float *cloud,
+                                        const int64_t *choose, const int64_t *obj, float *out_r, float *out_t, float *out_c, float *emb, void *ws,
+                                        size_t ws_bytes, df_stream_t stream) {
+  if (!h || as_net(h)->kind != 0) return set_error(DF_ERR_ARG, "not a PoseNet handle");
+  if (!img) return set_error(DF_ERR_ARG, "posenet_forward_multi: null pointer");
+  std::vector<Grp> gs;
+  int rc = make_groups(as_net(h), nb, B, H, W, img, gs);
+  if (rc != DF_OK) return rc;
+  if ((rc = check_ready(*as_net(h))) != DF_OK) return rc;
+  if (!cloud || !choose || !obj || !out_r || !out_t || !out_c || !emb || !ws) return set_error(DF_ERR_ARG, "posenet_forward_multi: null pointer");
+  if (df_posenet_multi_workspace_bytes(h, nb, B, H, W) > ws_bytes) return set_error(DF_ERR_WORKSPACE, "posenet_forward_multi: workspace too small");
+  Ctx c{as_net(h), to_stream(stream), false, static_cast<char *>(ws)};
+  c.cap = ws_bytes;
+  PoseNetOut o{out_r, out_t, out_c, emb};
+  posenet_forward(c, gs, cloud, choose, obj, o);
+  return finish(c, "posenet_forward_multi");
+}
+
 static void refiner_standalone(Ctx &c, int B, const float *x, const float *emb, const int64_t *obj, float *out_r, float *out_t) {
   const int N = c.net->num_points, Npad = round_up(N, 128);
   float *emb_pm = c.f((size_t)B * Npad * 32);

@@ -181,6 +181,41 @@ class PoseNet(_EngineModule):
         return out_r, out_t, out_c, emb
 
 
+    def forward_multi(self, imgs, x, choose, obj):
+        """``forward`` over crops of DIFFERENT sizes in one device-side pass (``df_posenet_forward_multi``), eval mode only.
+
+        ``imgs``: list of ``[B_i,3,H_i,W_i]`` tensors, one per crop-size bucket; ``x [sum B,N,3]``, ``choose [sum B,N]``, ``obj [sum B]``:
+        the objects of all buckets concatenated in bucket order.  Returns ``(out_rx, out_tx, out_cx, emb)`` in that order, bit-identical
+        to per-bucket ``forward`` calls -- the frozen estimator of the refiner phase (tools/train.py:139-145) over a whole window."""
+        import ctypes
+        self._check_mode()
+        imgs = [_dev_f32(i) for i in imgs]
+        x = _dev_f32(x)
+        dev, N, nb = x.device, self.num_points, len(imgs)
+        Bs = [int(i.shape[0]) for i in imgs]
+        Bt = sum(Bs)
+        if nb == 0 or any(i.dim() != 4 or i.shape[1] != 3 for i in imgs) or x.shape != (Bt, N, 3):
+            raise RuntimeError(f"PoseNet.forward_multi: need images [B_i,3,H_i,W_i] and x [{Bt},{N},3], got {[tuple(i.shape) for i in imgs]}, {tuple(x.shape)}")
+        choose = choose.to(device=dev, dtype=torch.int64).reshape(Bt, N).contiguous()
+        obj = obj.to(device=dev, dtype=torch.int64).reshape(Bt).contiguous()
+        out_r, out_t = torch.empty(Bt, N, 4, device=dev), torch.empty(Bt, N, 3, device=dev)
+        out_c, emb = torch.empty(Bt, N, 1, device=dev), torch.empty(Bt, 32, N, device=dev)
+        arr = ctypes.c_int * nb
+        cB, cH, cW = arr(*Bs), arr(*[int(i.shape[2]) for i in imgs]), arr(*[int(i.shape[3]) for i in imgs])
+        cimg = (ctypes.c_void_p * nb)(*[i.data_ptr() for i in imgs])
+        L = _lib.lib()
+        with _lib.device_guard(dev):
+            h = self._engine(dev)
+            need = L.df_posenet_multi_workspace_bytes(h, nb, cB, cH, cW)
+            if need == 0:
+                _lib.check(-1, "posenet_multi_workspace_bytes")
+            ws = self._workspace(need, dev)
+            st = L.df_posenet_forward_multi(h, nb, cB, cH, cW, cimg, x.data_ptr(), choose.data_ptr(), obj.data_ptr(), out_r.data_ptr(),
+                                            out_t.data_ptr(), out_c.data_ptr(), emb.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream())
+        _lib.check(st, "posenet_forward_multi")
+        return out_r, out_t, out_c, emb
+
+
 class PoseRefineNet(_EngineModule):
     """``PoseRefineNet(num_points, num_obj)`` (lib/network.py:170-185)."""
     _kind = "refiner"

@@ -95,6 +95,14 @@ int df_posenet_forward(df_net *net, int B, int H, int W, const float *img, const
                        const int64_t *obj, float *out_r, float *out_t, float *out_c, float *emb, void *ws,
                        size_t ws_bytes, df_stream_t stream);
 
+/* The same forward for nb buckets of different crop sizes in one pass: bucket i holds B[i] objects of H[i] x W[i] (img[i]:
+ * [B[i]][3][H[i]][W[i]]); cloud / choose / obj / outputs are concatenated in bucket order.  Bit-identical to per-bucket
+ * df_posenet_forward calls.  (The frozen estimator of the refiner phase, tools/train.py:139-145, over a whole window.) */
+size_t df_posenet_multi_workspace_bytes(const df_net *net, int nb, const int *B, const int *H, const int *W);
+int df_posenet_forward_multi(df_net *net, int nb, const int *B, const int *H, const int *W, const float *const *img,
+                             const float *cloud, const int64_t *choose, const int64_t *obj, float *out_r, float *out_t,
+                             float *out_c, float *emb, void *ws, size_t ws_bytes, df_stream_t stream);
+
 /* Batched PoseRefineNet.forward (lib/network.py:187-206): x [B][N][3], emb [B][32][N], obj [B]
  * -> out_r [B][4], out_t [B][3]. */
 size_t df_refiner_workspace_bytes(const df_net *net, int B);

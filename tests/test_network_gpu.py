@@ -287,6 +287,31 @@ def test_multi_bucket_call_equals_per_bucket_calls():
         pe.estimate_multi([T(bs[0], "img")], cat("cloud"), cat("choose"), cat("obj"), 2)      # object counts disagree
 
 
+def test_multi_bucket_forward_equals_per_bucket_forwards():
+    """df_posenet_forward_multi (PoseNet.forward_multi): the four heads of the full forward for a window of mixed crop sizes in one pass ==
+    one forward per crop size, bit for bit (what the refiner phase of tools/train.py asks of its frozen estimator)."""
+    K, N = 21, 1000
+    est, _ = _nets(K, N, 13)
+    shapes = [(3, 80, 80), (2, 120, 160), (1, 92, 108), (2, 160, 160)]
+    bs = [synth.make_batch(700 + i, B, H, W, N, K) for i, (B, H, W) in enumerate(shapes)]
+    T = lambda b, k: torch.from_numpy(b[k]).cuda()
+    cat = lambda k: torch.cat([T(b, k) for b in bs])
+    outs = est.forward_multi([T(b, "img") for b in bs], cat("cloud"), cat("choose"), cat("obj"))
+    assert [tuple(o.shape) for o in outs] == [(8, N, 4), (8, N, 3), (8, N, 1), (8, 32, N)]
+    o = 0
+    for b, (B, H, W) in zip(bs, shapes):
+        one = est(T(b, "img"), T(b, "cloud"), T(b, "choose"), T(b, "obj"))
+        for a, m in zip(one, outs):
+            assert torch.equal(a, m[o:o + B]), (H, W)
+        o += B
+    with pytest.raises(RuntimeError):
+        est.forward_multi([T(bs[0], "img")], cat("cloud"), cat("choose"), cat("obj"))      # object counts disagree
+    est.train()
+    with pytest.raises(RuntimeError):
+        est.forward_multi([T(b, "img") for b in bs], cat("cloud"), cat("choose"), cat("obj"))  # inference-only entry point
+    est.eval()
+
+
 def test_a_window_with_more_than_64_crop_sizes():
     """40-pixel snapping yields up to 12 x 16 crop sizes, so a long evaluation window can hold more than 64 of them (the limit of
     df_estimate_poses_multi until round 3): 70 one-object buckets in one call == the same objects evaluated size by size."""

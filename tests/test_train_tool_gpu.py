@@ -153,9 +153,11 @@ def test_two_rank_resume_of_the_estimator_alone_keeps_the_refiners_in_sync(tmp_p
     assert "different weights" not in out.stdout and out.stdout.count("TEST FINISH") >= 1, out.stdout[-3000:]
 
 
-def test_refiner_phase_on_lanes_matches_one_lane(tmp_path):
-    """The refiner phase with the frames of a window on 3 lanes (own refiner step AND own copy of the frozen estimator per lane) trains
-    the same refiner as one lane: same data order, gradients summed in lane order (a different summation order: tolerance, not bits)."""
+def test_refiner_phase_as_one_window_and_on_lanes_matches_one_frame_at_a_time(tmp_path):
+    """The refiner phase three ways: one frame at a time (--passes lanes --lanes 1, the reference's bs = 1 loop), the frames of a window on 3
+    lanes (own refiner step AND own copy of the frozen estimator per lane), and the default --passes window (the frozen estimator over the
+    window's mixed crop sizes in ONE multi-bucket forward, then the refiner steps over all frames at once).  Same data order, the same
+    refiner after an epoch: a different summation order of the window's gradient only (tolerance, not bits)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import train
     from densefusion_amd import synth
@@ -164,21 +166,22 @@ def test_refiner_phase_on_lanes_matches_one_lane(tmp_path):
     torch.save({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.posenet_spec(3), 5).items()}, tmp_path / "ck" / "p.pth")
     torch.save({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.refiner_spec(3), 6).items()}, tmp_path / "ck" / "r.pth")
     got = {}
-    for lanes in (1, 3):
-        out = tmp_path / f"m{lanes}"
+    for name, flags in (("one", ["--passes", "lanes", "--lanes", "1"]), ("lanes3", ["--passes", "lanes", "--lanes", "3"]), ("window", ["--passes", "window"])):
+        out = tmp_path / f"m_{name}"
         os.makedirs(out)
         for f in ("p.pth", "r.pth"):
             os.link(tmp_path / "ck" / f, out / f)
         train.main(["--dataset", "synthetic", "--num_objects", "3", "--num_points", "64", "--synthetic_train_frames", "24", "--synthetic_test_frames", "2",
                     "--batch_size", "12", "--nepoch", "2", "--resume_posenet", "p.pth", "--resume_refinenet", "r.pth", "--decay_margin", "1e9",
-                    "--refine_margin", "1e9", "--lanes", str(lanes), "--outf", str(out), "--log_dir", str(tmp_path / f"l{lanes}")])
+                    "--refine_margin", "1e9", "--outf", str(out), "--log_dir", str(tmp_path / f"l_{name}")] + flags)
         ck = glob.glob(str(out / "pose_refine_model_1_*.pth"))
         assert ck, os.listdir(out)
-        got[lanes] = torch.load(ck[0], map_location="cpu", weights_only=True)
+        got[name] = torch.load(ck[0], map_location="cpu", weights_only=True)
     moved = 0.0
     start = torch.load(tmp_path / "ck" / "r.pth", weights_only=True)
-    for k in got[1]:
-        a, b = got[1][k].double(), got[3][k].double()
+    for k in got["one"]:
+        a = got["one"][k].double()
         moved = max(moved, float((a - start[k].double()).abs().max()))
-        assert float((a - b).abs().max()) <= 2e-5 + 2e-3 * float((a - start[k].double()).abs().max()), k
+        for other in ("lanes3", "window"):
+            assert float((a - got[other][k].double()).abs().max()) <= 2e-5 + 2e-3 * float((a - start[k].double()).abs().max()), (other, k)
     assert moved > 1e-5                                                                      # it trained

@@ -85,9 +85,10 @@ def build_parser():
                          "host thread, workspace and gradient buffer each; gradients summed in lane order): bs = 1 passes fill a fraction "
                          "of the chip, so independent frames overlap.  1 = one pass at a time")
     ap.add_argument("--passes", type=str, default="window", choices=["window", "lanes"],
-                    help="PoseNet phase, native step.  window (default): the frames of an accumulation window, whatever their crop sizes, run as ONE "
+                    help="native step.  window (default): the frames of an accumulation window, whatever their crop sizes, run as ONE "
                          "multi-bucket pass (df_posenet_train_step_multi: per-point layers, 1x1 / Winograd-domain products and every weight gradient "
-                         "once over all frames); lanes: one pass per --frames_per_pass frames of equal size, spread over --lanes concurrent lanes")
+                         "once over all frames; in the refiner phase: df_posenet_forward_multi for the frozen estimator, then the refiner steps over "
+                         "all frames of the window); lanes: one pass per --frames_per_pass frames of equal size, spread over --lanes concurrent lanes")
     ap.add_argument("--window_pixels", type=int, default=1 << 21,
                     help="--passes window: a window whose crops add up to more pixels than this is cut into several passes (bounds the workspace: "
                          "about 4.6 KB per crop pixel)")
@@ -222,10 +223,11 @@ def main(argv=None):
     def start_refine_lanes():
         """Refiner phase on lanes: every lane gets its own refiner step (workspace, gradient buffer) AND its own copy of the frozen
         estimator (engine handle + workspace are per module), so the frames of a window run side by side like the PoseNet phase's."""
-        if not native or opt.lanes <= 1 or refine_lanes:
+        if native and not refine_lanes:
+            sync_module(estimator)
+        if not native or opt.lanes <= 1 or refine_lanes or opt.passes != "lanes":
             return
         from densefusion_amd.native_train import Lanes
-        sync_module(estimator)
         rl = Lanes(native["refiner"], opt.lanes)
         rl.lanes[0].frozen_estimator = estimator
         for lane in rl.lanes[1:]:
@@ -319,6 +321,29 @@ def main(argv=None):
             sym = [train_utils.host_index(f[5]) in opt.sym_list for f in order]
             dists.append(native["posenet"].step_posenet_multi(imgs, cat(0), cat(1), cat(5), cat(3), cat(4), sym, opt.w, dropout=True)["dis"])
         return torch.cat(dists)
+
+    def _run_window_refine_native(frames):
+        """Refiner phase (tools/train.py:139-159) on a whole window: the frozen estimator over all crop sizes in one multi-bucket forward of the
+        inference engine, the arg-max-confidence re-centring per frame (Loss with refine=True), then `iteration` native refiner steps over
+        ALL frames of the window at once (the refiner sees num_points points per frame whatever the crop size)."""
+        by_size = {}
+        for f in frames:
+            by_size.setdefault(tuple(f[2].shape[-2:]), []).append(f)
+        order = [f for group in by_size.values() for f in group]
+        cat = lambda k: torch.cat([f[k] for f in order])
+        idx, model_points = cat(5), cat(4)
+        sym = [train_utils.host_index(f[5]) in opt.sym_list for f in order]
+        with torch.no_grad():
+            pred_r, pred_t, pred_c, emb = estimator.forward_multi([torch.cat([f[2] for f in group]) for group in by_size.values()], cat(0), cat(1), idx)
+            new_points, new_target = [], []
+            for b, f in enumerate(order):
+                _, _, npt, ntg = criterion(pred_r[b:b + 1], pred_t[b:b + 1], pred_c[b:b + 1], f[3], f[4], f[5], f[0], opt.w, True)
+                new_points.append(npt); new_target.append(ntg)
+            new_points, new_target = torch.cat(new_points), torch.cat(new_target)
+        for _ in range(opt.iteration):
+            out = native["refiner"].step_refiner(new_points, emb, idx, new_target, model_points, sym)
+            new_points, new_target = out["new_points"], out["new_target"]
+        return out["dis"]
 
     def _run_pass(frames):
         points, choose, img = (torch.cat([f[k] for f in frames]) for k in (0, 1, 2))
@@ -427,9 +452,9 @@ def main(argv=None):
                 by_size.setdefault(tuple(f[2].shape[-2:]), []).append(f)
             passes = [group[g0:g0 + max(1, opt.frames_per_pass)] for group in by_size.values() for g0 in range(0, len(group), max(1, opt.frames_per_pass))]
             active = (refine_lanes[0] if refine_lanes else None) if opt.refine_start else lanes
-            if native and not opt.refine_start and opt.passes == "window":
+            if native and opt.passes == "window":
                 if window:
-                    window_dis = window_dis + _run_window_native(window).sum()
+                    window_dis = window_dis + (_run_window_refine_native if opt.refine_start else _run_window_native)(window).sum()
             elif active is not None:
                 for d in active.run([(lambda lane, fs=fs: _run_pass_native(fs, lane)) for fs in passes]):
                     window_dis = window_dis + d.sum()
