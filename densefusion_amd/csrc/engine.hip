@@ -371,7 +371,13 @@ struct Ctx {
       }
       hipEventRecord(n.ev[n.ev_used], st);
     }
+#ifdef DF_DEV
+    ConvParams pc = p;
+    pc.wgt_const = true;           // the engine's packed parameters: split_gemm_invalidate() on every load / destroy
+    const int rc = launch_conv(pc, st);
+#else
     const int rc = launch_conv(p, st);
+#endif
     if (n.profiling) {
       hipEventRecord(n.ev[n.ev_used + 1], st);
       n.ev_flops.push_back(conv_flops(p));
@@ -834,6 +840,9 @@ extern "C" df_net *df_refiner_create(int num_points, int num_obj) {
 extern "C" void df_net_destroy(df_net *h) {
   if (!h) return;
   Net *n = as_net(h);
+#ifdef DF_DEV
+  split_gemm_invalidate();
+#endif
   for (auto &kv : n->buf) hipFree(kv.second);
   if (n->stage) hipFree(n->stage);
   for (auto &kv : n->taps) if (kv.second.buf) hipFree(kv.second.buf);
@@ -856,6 +865,9 @@ extern "C" int df_net_param_info(const df_net *h, int i, char *key_out, int key_
 
 extern "C" int df_net_load_param(df_net *h, const char *key, const float *ptr, int64_t numel) {
   if (!h || !key) return set_error(DF_ERR_ARG, "load_param: null handle/key");
+#ifdef DF_DEV
+  split_gemm_invalidate();
+#endif
   return load_param(*as_net(h), key, ptr, numel);
 }
 

@@ -37,6 +37,9 @@ struct ConvParams {
   // split-K (training path only: opt-in through a caller-provided scratch, df_conv_desc.splitk_ws): launches that would fill less than
   // half the chip cut their reduction into `splitk` ranges (blockIdx.z), partial sums go to the scratch and a fixed-order reduce
   // kernel adds them and applies bias / residual / activation (deterministic).  splitk is set by launch_conv.
+  // development build only (csrc/split_gemm.hip): the weights do not change between split_gemm_invalidate() calls, so their bf16 planes
+  // may be cached (set by the inference engine for its own packed parameters); false: the planes are cut again on every launch
+  bool wgt_const = false;
   float *splitk_ws = nullptr;
   size_t splitk_ws_bytes = 0;
   int splitk = 1;
@@ -83,5 +86,11 @@ constexpr int WGRAD_MAX_SEGS = 32;
 size_t wgrad_multi_workspace_bytes(const ConvParams &p, int nseg, const WgradSeg *segs);
 int launch_wgrad_multi(const ConvParams &p, int nseg, const WgradSeg *segs, float *dw, float *db, void *ws, size_t ws_bytes, hipStream_t st,
                        int accumulate = 0);
+
+#ifdef DF_DEV
+// development build only (csrc/split_gemm.hip): DF_GEMM_SPLIT_BF16=1 routes eligible plain-GEMM launches to the bf16 x 6 experiment
+bool try_split_gemm(const ConvParams &p, hipStream_t st);
+void split_gemm_invalidate();      // cached weight planes are cut again at their next use (a parameter was loaded / a network destroyed)
+#endif
 
 }  // namespace df

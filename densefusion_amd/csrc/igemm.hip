@@ -1398,6 +1398,12 @@ int launch_conv(const ConvParams &p, hipStream_t st, int *splitk_used) {
   if (M <= 0 || p.Cout <= 0) return DF_OK;
   if (M * (long)p.out_ld >= (1L << 40) || (long)p.B * p.H * p.W >= (1L << 31))
     return set_error(DF_ERR_ARG, "conv: tensor too large for 32-bit pixel indexing");
+#ifdef DF_DEV
+  if (!p.splitk_ws && try_split_gemm(p, st)) {
+    if (splitk_used) *splitk_used = 1;
+    return check_launch("split gemm");
+  }
+#endif
   const TileCfg c = pick_cfg(p);
   ConvParams pl = p;       // launch copy: + the column-tile group width and the division magics
   make_fdiv((long)p.OH * p.OW, pl.ohw_magic, pl.ohw_sh);
