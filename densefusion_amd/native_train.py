@@ -117,6 +117,24 @@ class NativeTrainer:
             raise RuntimeError("symmetric flags: one per frame")
         return (ctypes.c_int * B)(*vals)
 
+    def _next_seed(self):
+        """Dropout2d seed of this call: a 64-bit mix of (torch's seed, the lane, the call number) -- distinct per lane and call (an additive
+        lane offset would meet another lane's sequence after enough calls), reproducible for a given torch.manual_seed."""
+        self._calls += 1
+        m = (1 << 64) - 1
+        x = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + (self._salt + 1) * 0xD1B54A32D192ED03 + self._calls) & m
+        x ^= x >> 30; x = (x * 0xBF58476D1CE4E5B9) & m
+        x ^= x >> 27; x = (x * 0x94D049BB133111EB) & m
+        x ^= x >> 31
+        return x & 0x3FFFFFFF
+
+    @staticmethod
+    def _check_graph_dropout(graph_safe, dropout, seed):
+        # the seed is a by-value launch argument: a captured step replays the SAME three channel masks on every replay
+        if graph_safe and dropout and seed is None:
+            raise RuntimeError("graph_safe=True with dropout=True would freeze the Dropout2d masks into the captured graph: pass dropout=False, "
+                               "or an explicit seed if one fixed mask set per capture is what you want")
+
     # ---- PoseNet + Loss (tools/train.py:152-153,161) ----
     def step_posenet(self, img, cloud, choose, obj, target, model_points, symmetric, w, dropout=True, seed=None, want_pred=False,
                      graph_safe=False):
@@ -137,9 +155,9 @@ class NativeTrainer:
                    new_target=torch.empty(B, M, 3, device=dev), emb=torch.empty(B, 32, N, device=dev))
         if want_pred:
             out.update(pred_r=torch.empty(B, N, 4, device=dev), pred_t=torch.empty(B, N, 3, device=dev), pred_c=torch.empty(B, N, 1, device=dev))
-        self._calls += 1
+        self._check_graph_dropout(graph_safe, dropout, seed)
         if seed is None:
-            seed = (int(torch.initial_seed() % 100003) * 7919 + self._calls + self._salt) & 0x3FFFFFFF
+            seed = self._next_seed()
         P = lambda k: out[k].data_ptr() if k in out else None
         L = _lib.lib()
         with _lib.device_guard(dev):
@@ -177,9 +195,9 @@ class NativeTrainer:
                    new_target=torch.empty(B, M, 3, device=dev), emb=torch.empty(B, 32, N, device=dev))
         if want_pred:
             out.update(pred_r=torch.empty(B, N, 4, device=dev), pred_t=torch.empty(B, N, 3, device=dev), pred_c=torch.empty(B, N, 1, device=dev))
-        self._calls += 1
+        self._check_graph_dropout(graph_safe, dropout, seed)
         if seed is None:
-            seed = (int(torch.initial_seed() % 100003) * 7919 + self._calls + self._salt) & 0x3FFFFFFF
+            seed = self._next_seed()
         P = lambda k: out[k].data_ptr() if k in out else None
         arr = ctypes.c_int * nb
         cB, cH, cW = arr(*Bs), arr(*[int(i.shape[2]) for i in imgs]), arr(*[int(i.shape[3]) for i in imgs])
@@ -265,7 +283,7 @@ class Lanes:
         self.tr, self.n = trainer, max(1, int(n))
         self.lanes = [trainer] + [NativeTrainer(trainer.kind, trainer.num_points, trainer.num_obj, trainer.device) for _ in range(self.n - 1)]
         for li, lane in enumerate(self.lanes):
-            lane._salt = li * 1_000_003
+            lane._salt = li                       # mixed into the seed hash (_next_seed)
         from .streams import concurrent_streams
         self.streams = concurrent_streams(trainer.device, self.n)      # tested to run side by side (streams.py)
         self.pool = ThreadPoolExecutor(max_workers=self.n, thread_name_prefix="df-lane") if self.n > 1 else None

@@ -215,6 +215,14 @@ def test_native_step_at_the_ycb_training_shape_with_adam_and_a_hipgraph():
     torch.cuda.synchronize()
     assert torch.equal(tr.grad, eager)
     _close(captured["loss"], out["loss"], 1e-6, "replayed loss")
+    # a captured step would replay ONE set of Dropout2d masks for ever (the seed is a by-value launch argument): refused unless asked for
+    with pytest.raises(RuntimeError, match="freeze the Dropout2d masks"):
+        tr.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], sym, 0.015, dropout=True, graph_safe=True)
+    # default seeds: a hash of (torch seed, lane, call) -- no two equal across lanes and calls
+    a, b = _trainer("posenet", N, K, sd), _trainer("posenet", N, K, sd)
+    b._salt = 1
+    seeds = [t._next_seed() for _ in range(2000) for t in (a, b)]
+    assert len(set(seeds)) == len(seeds)
     # one Adam step on the flat buffers (kernel layout: Adam is element-wise) lowers this batch's loss
     opt = train_utils.FlatAdam(tr, lr=1e-4)
     v0 = tr.version
