@@ -185,3 +185,25 @@ def test_refiner_phase_as_one_window_and_on_lanes_matches_one_frame_at_a_time(tm
         for other in ("lanes3", "window"):
             assert float((a - got[other][k].double()).abs().max()) <= 2e-5 + 2e-3 * float((a - start[k].double()).abs().max()), (other, k)
     assert moved > 1e-5                                                                      # it trained
+
+
+def test_a_window_larger_than_window_pixels_is_cut_into_passes(tmp_path, caplog):
+    """--window_pixels bounds the workspace: a window whose crops add up to more pixels runs as several multi-bucket passes (PoseNet phase) /
+    several estimator forwards (refiner phase); the optimizer still steps once per window and both phases produce sane distances."""
+    import logging
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import train
+    from densefusion_amd import synth
+    train.SyntheticPoseDataset.CROPS = [(40, 40), (80, 40), (40, 80)]
+    os.makedirs(tmp_path / "m", exist_ok=True)
+    torch.save({k: torch.from_numpy(v) for k, v in synth.make_state_dict(synth.posenet_spec(3), 5).items()}, tmp_path / "m" / "p.pth")
+    common = ["--dataset", "synthetic", "--num_objects", "3", "--num_points", "64", "--synthetic_train_frames", "24", "--synthetic_test_frames", "2",
+              "--batch_size", "12", "--nepoch", "3", "--resume_posenet", "p.pth", "--decay_margin", "-1", "--outf", str(tmp_path / "m"),
+              "--log_dir", str(tmp_path / "l"), "--window_pixels", "4000"]                     # 1-2 frames per pass
+    for extra in (["--refine_margin", "-1"], ["--refine_margin", "1e9"]):                       # PoseNet phase only / refiner phase from epoch 2
+        caplog.clear()
+        with caplog.at_level(logging.INFO, logger="train"):
+            best = train.main(common + extra)
+        lines = [r.getMessage() for r in caplog.records]
+        batches = [float(ln.split("Avg_dis:")[1]) for ln in lines if ln.startswith("Train time") and "Batch" in ln]
+        assert best == best and 1e-5 < best < 10 and len(batches) >= 4 and all(0 < b < 10 for b in batches), (best, batches)

@@ -299,19 +299,23 @@ def main(argv=None):
             new_points, new_target = out["new_points"], out["new_target"]
         return out["dis"]
 
-    def _run_window_native(frames):
-        """PoseNet phase: the frames of a window (any crop sizes) as multi-bucket passes of at most --window_pixels crop pixels each; returns
-        the frames' distances (device tensor)."""
+    def _pixel_chunks(frames, limit):
+        """`frames` cut into runs of at most `limit` crop pixels (at least one frame each)"""
         chunks, cur, px = [], [], 0
         for f in frames:
             n = int(f[2].shape[-2]) * int(f[2].shape[-1])
-            if cur and px + n > opt.window_pixels:
+            if cur and px + n > limit:
                 chunks.append(cur); cur, px = [], 0
             cur.append(f); px += n
         if cur:
             chunks.append(cur)
+        return chunks
+
+    def _run_window_native(frames):
+        """PoseNet phase: the frames of a window (any crop sizes) as multi-bucket passes of at most --window_pixels crop pixels each; returns
+        the frames' distances (device tensor)."""
         dists = []
-        for chunk in chunks:
+        for chunk in _pixel_chunks(frames, opt.window_pixels):
             by_size = {}
             for f in chunk:
                 by_size.setdefault(tuple(f[2].shape[-2:]), []).append(f)
@@ -323,23 +327,26 @@ def main(argv=None):
         return torch.cat(dists)
 
     def _run_window_refine_native(frames):
-        """Refiner phase (tools/train.py:139-159) on a whole window: the frozen estimator over all crop sizes in one multi-bucket forward of the
-        inference engine, the arg-max-confidence re-centring per frame (Loss with refine=True), then `iteration` native refiner steps over
-        ALL frames of the window at once (the refiner sees num_points points per frame whatever the crop size)."""
-        by_size = {}
-        for f in frames:
-            by_size.setdefault(tuple(f[2].shape[-2:]), []).append(f)
-        order = [f for group in by_size.values() for f in group]
-        cat = lambda k: torch.cat([f[k] for f in order])
-        idx, model_points = cat(5), cat(4)
-        sym = [train_utils.host_index(f[5]) in opt.sym_list for f in order]
+        """Refiner phase (tools/train.py:139-159) on a whole window: the frozen estimator over all crop sizes in multi-bucket forwards of the
+        inference engine (at most 2 x --window_pixels crop pixels each: the engine keeps no activations), the arg-max-confidence re-centring per
+        frame (Loss with refine=True), then `iteration` native refiner steps over ALL frames of the window at once (the refiner sees num_points
+        points per frame whatever the crop size)."""
+        order, emb, new_points, new_target = [], [], [], []
         with torch.no_grad():
-            pred_r, pred_t, pred_c, emb = estimator.forward_multi([torch.cat([f[2] for f in group]) for group in by_size.values()], cat(0), cat(1), idx)
-            new_points, new_target = [], []
-            for b, f in enumerate(order):
-                _, _, npt, ntg = criterion(pred_r[b:b + 1], pred_t[b:b + 1], pred_c[b:b + 1], f[3], f[4], f[5], f[0], opt.w, True)
-                new_points.append(npt); new_target.append(ntg)
-            new_points, new_target = torch.cat(new_points), torch.cat(new_target)
+            for chunk in _pixel_chunks(frames, 2 * opt.window_pixels):
+                by_size = {}
+                for f in chunk:
+                    by_size.setdefault(tuple(f[2].shape[-2:]), []).append(f)
+                part = [f for group in by_size.values() for f in group]
+                cat = lambda k: torch.cat([f[k] for f in part])
+                pred_r, pred_t, pred_c, e = estimator.forward_multi([torch.cat([f[2] for f in group]) for group in by_size.values()], cat(0), cat(1), cat(5))
+                for b, f in enumerate(part):
+                    _, _, npt, ntg = criterion(pred_r[b:b + 1], pred_t[b:b + 1], pred_c[b:b + 1], f[3], f[4], f[5], f[0], opt.w, True)
+                    new_points.append(npt); new_target.append(ntg)
+                order += part; emb.append(e)
+            new_points, new_target, emb = torch.cat(new_points), torch.cat(new_target), torch.cat(emb)
+        idx, model_points = torch.cat([f[5] for f in order]), torch.cat([f[4] for f in order])
+        sym = [train_utils.host_index(f[5]) in opt.sym_list for f in order]
         for _ in range(opt.iteration):
             out = native["refiner"].step_refiner(new_points, emb, idx, new_target, model_points, sym)
             new_points, new_target = out["new_points"], out["new_target"]
