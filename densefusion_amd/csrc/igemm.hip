@@ -1302,8 +1302,10 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float *__restrict_
   const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   __shared__ float s[4][64];
   float a = 0.f;
-  if (c < C)
-    for (int r = r0 + part; r < r1; r += 4) a += dy[(size_t)r * ld + coff + c];
+  if (c < C) {
+#pragma unroll 8
+    for (int r = r0 + part; r < r1; r += 4) a += dy[(size_t)r * ld + coff + c];      // (loads ahead, the additions in row order)
+  }
   s[part][threadIdx.x & 63] = a;
   __syncthreads();
   if (part == 0 && c < C) db[(size_t)blockIdx.y * C + c] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
@@ -1588,7 +1590,7 @@ int launch_conv_multi(const ConvParams &p, int nseg, const WgradSeg *segs, hipSt
 }
 
 namespace {
-struct WgradPlan { bool big; int tiles, split, chunk, steps, nblk; size_t part_floats, bias_floats; };
+struct WgradPlan { bool big; int tiles, split, chunk, steps, nblk, bias_rows; size_t part_floats, bias_floats; };
 
 // big kernel: the pixel axis is a sequence of 32-pixel steps (per bucket: ceil(M_g / 32)), cut into `split` chunks of `steps` steps each;
 // small kernel: chunks of `chunk` = 32 * steps pixels per bucket
@@ -1617,7 +1619,10 @@ WgradPlan wgrad_plan(const ConvParams &p, int nseg, const WgradSeg *segs) {
     w.split = 0;
     for (int g = 0; g < nseg; ++g) w.split += (int)(((long)segs[g].B * segs[g].OH * segs[g].OW + w.chunk - 1) / w.chunk);
   }
-  w.nblk = (int)((M + 127) / 128);
+  // column sums of dY (the bias gradient): row blocks of 128 rows, or of the multiple of 128 that leaves at most 256 blocks -- the second stage
+  // walks the blocks 8 lanes per channel (1 600 blocks at 204 800 pixel rows took it 47 us)
+  w.bias_rows = 128 * (int)(((M + 127) / 128 + 255) / 256);
+  w.nblk = (int)((M + w.bias_rows - 1) / w.bias_rows);
   w.part_floats = (size_t)w.split * p.Cout * K;       // (a single slice goes straight to dw unless the launch accumulates)
   w.bias_floats = (size_t)w.nblk * p.Cout;
   return w;
@@ -1711,7 +1716,7 @@ static int launch_wgrad_segs(ConvParams p, int nseg, const WgradSeg *segs, float
   }
   if (db) {     // dY's rows of all buckets are contiguous: one column sum over them
     const float *dy = p.out + out_lo * p.out_ld;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3((p.Cout + 63) / 64, w.nblk), dim3(256), 0, st, dy, (int)M, p.Cout, p.out_ld, p.out_coff, bpart, 128);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((p.Cout + 63) / 64, w.nblk), dim3(256), 0, st, dy, (int)M, p.Cout, p.out_ld, p.out_coff, bpart, w.bias_rows);
     hipLaunchKernelGGL(bias_reduce_kernel, dim3((p.Cout + 31) / 32), dim3(256), 0, st, bpart, db, p.Cout, w.nblk, accumulate);
   }
   return check_launch("wgrad");
