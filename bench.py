@@ -527,7 +527,7 @@ def bench_train(device):
     out["frames_per_s"]["window_of_32_mixed_crop_sizes"] = round(3 * 32 / (time.perf_counter() - t0), 1)
 
     # refiner phase (tools/train.py:139-159 of the reference; batch_size / iteration = 16 frames per optimizer step at this fork's defaults): the
-    # frozen estimator over the window's mixed crop sizes in one multi-bucket forward, Loss(refine=True) per frame, then `iteration` = 2 native
+    # frozen estimator over the window's mixed crop sizes in one multi-bucket forward, Loss(refine=True) for all frames in one call, then `iteration` = 2 native
     # refiner steps over all 16 frames -- what tools/train.py --refine_start runs per window
     from densefusion_amd.lib.network import PoseNet as _PoseNet
     est = _PoseNet(N, K); est.load_state_dict(sd); est = est.to(device).eval()
@@ -540,17 +540,14 @@ def bench_train(device):
     for f in rframes:
         by_size.setdefault(tuple(f["img"].shape[-2:]), []).append(f)
     rorder = [f for g in by_size.values() for f in g]
+    robj = [int(f["obj"].reshape(-1)[0]) for f in rorder]          # host object indices (the loader's hint in tools/train.py: no read-back in the loop)
 
     def refine_window():
         stack = lambda k: torch.stack([f[k] for f in rorder])
         obj, mp = stack("obj"), stack("model_points")
         with torch.no_grad():
             pr, pt, pc, emb = est.forward_multi([torch.stack([f["img"] for f in g]) for g in by_size.values()], stack("cloud"), stack("choose"), obj)
-            npts, ntg = [], []
-            for b, f in enumerate(rorder):
-                _, _, a, t = crit(pr[b:b + 1], pt[b:b + 1], pc[b:b + 1], f["target"][None], f["model_points"][None], f["obj"][None], f["cloud"][None], 0.015, True)
-                npts.append(a); ntg.append(t)
-            npts, ntg = torch.cat(npts), torch.cat(ntg)
+            _, _, npts, ntg = crit.forward_frames(pr, pt, pc, stack("target"), mp, robj, stack("cloud"), 0.015, True)
         for _ in range(2):
             o = rtr.step_refiner(npts, emb, obj, ntg, mp, [f["symmetric"] for f in rorder])
             npts, ntg = o["new_points"], o["new_target"]

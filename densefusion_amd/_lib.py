@@ -49,6 +49,7 @@ SIGNATURES = {
     "df_estimate_multi_workspace_bytes": (_sz, [_vp, _vp, _i, _vp, _vp, _vp]),
     "df_estimate_poses_multi": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "df_loss_forward": (_i, [_vp] * 6 + [_i, _i, _f, _i] + [_vp] * 7),
+    "df_loss_forward_frames": (_i, [_i] + [_vp] * 7 + [_i, _i, _f] + [_vp] * 7),
     "df_loss_refine_forward": (_i, [_vp] * 5 + [_i, _i, _i] + [_vp] * 5),
     "df_loss_backward": (_i, [_vp] * 8 + [_i, _i, _f, _f] + [_vp] * 4),
     "df_loss_refine_backward": (_i, [_vp] * 5 + [_i, _f] + [_vp] * 3),

@@ -12,11 +12,19 @@
 
 #include "common.h"
 #include "knn_core.h"
+#include "loss.h"
 
 namespace df {
 namespace {
 
 constexpr int LB = 256;
+
+// Several frames in ONE launch (the training step's loss: B frames of N per-point poses, lib/loss.py is called once per frame): blockIdx.y picks
+// the frame idx[blockIdx.y]; every per-frame tensor starts at frame * its per-frame element count (frames are stacked, [B][N][..] / [B][M][3]).
+// Single-frame entry points pass {1, N, M, {0}}.  Each frame's arithmetic is exactly the single-frame launch's.
+constexpr int LOSS_MAX_FRAMES = 60;
+struct FrameTab { int n, N, M; int idx[LOSS_MAX_FRAMES]; };
+inline FrameTab one_frame(int N, int M) { FrameTab f{}; f.n = 1; f.N = N; f.M = M; f.idx[0] = 0; return f; }
 
 struct Rot { float m[9]; };
 
@@ -55,10 +63,16 @@ __device__ inline float block_sum(float v, float *s_red) {
 __global__ __launch_bounds__(LB) void add_dis_kernel(const float *__restrict__ pred_r, const float *__restrict__ pred_t,
                                                      const float *__restrict__ points, const float *__restrict__ target,
                                                      const float *__restrict__ model, int M, int symmetric,
-                                                     float *__restrict__ dis, int *__restrict__ sel_out) {
+                                                     float *__restrict__ dis, int *__restrict__ sel_out, const FrameTab ft) {
   extern __shared__ __attribute__((aligned(16))) float s_tgt[];   // [M][4]
   __shared__ float s_red[LB];
   const int p = blockIdx.x, tid = threadIdx.x;
+  {
+    const size_t f = ft.idx[blockIdx.y], fn = f * ft.N;
+    pred_r += fn * 4; pred_t += fn * 3; target += f * ft.M * 3; model += f * ft.M * 3; dis += fn;
+    if (points) points += fn * 3;
+    if (sel_out) sel_out += fn * ft.M;
+  }
   for (int m = tid; m < M; m += LB)
     reinterpret_cast<float4 *>(s_tgt)[m] = make_float4(target[m * 3], target[m * 3 + 1], target[m * 3 + 2], 0.f);
   const Rot R = quat_rot(pred_r + p * 4);
@@ -107,9 +121,15 @@ constexpr int SYM_QPL = 2;      // queries per lane (the scalar-cache scan's bes
 __global__ __launch_bounds__(LB) void add_dis_sym_kernel(const float *__restrict__ pred_r, const float *__restrict__ pred_t,
                                                          const float *__restrict__ points, const float *__restrict__ target,
                                                          const float *__restrict__ model, int P, int M, int ppb,
-                                                         float *__restrict__ dis, int *__restrict__ sel_out) {
+                                                         float *__restrict__ dis, int *__restrict__ sel_out, const FrameTab ft) {
   extern __shared__ __attribute__((aligned(16))) float s_e[];   // LB*SYM_QPL distances, then ppb totals
   __shared__ float s_red[LB];
+  {
+    const size_t f = ft.idx[blockIdx.y], fn = f * ft.N;
+    pred_r += fn * 4; pred_t += fn * 3; target += f * ft.M * 3; model += f * ft.M * 3; dis += fn;
+    if (points) points += fn * 3;
+    if (sel_out) sel_out += fn * ft.M;
+  }
   float *s_tot = s_e + LB * SYM_QPL;
   const int tid = threadIdx.x;
   const int p0 = blockIdx.x * ppb, np = min(ppb, P - p0);
@@ -167,9 +187,16 @@ __global__ __launch_bounds__(LB) void add_dis_bwd_kernel(const float *__restrict
                                                          const float *__restrict__ points, const float *__restrict__ target,
                                                          const float *__restrict__ model, const int *__restrict__ sel, int M,
                                                          const float *__restrict__ wgt, float wscale, float *__restrict__ d_r,
-                                                         float *__restrict__ d_t) {
+                                                         float *__restrict__ d_t, const FrameTab ft) {
   __shared__ float s_acc[12][LB];
   const int p = blockIdx.x, tid = threadIdx.x;
+  {
+    const size_t f = ft.idx[blockIdx.y], fn = f * ft.N;
+    pred_r += fn * 4; pred_t += fn * 3; target += f * ft.M * 3; model += f * ft.M * 3; d_r += fn * 4; d_t += fn * 3;
+    if (points) points += fn * 3;
+    if (wgt) wgt += fn;
+    if (sel) sel += fn * ft.M;
+  }
   const Rot R = quat_rot(pred_r + p * 4);
   float t0 = pred_t[p * 3], t1 = pred_t[p * 3 + 1], t2 = pred_t[p * 3 + 2];
   if (points) { t0 = points[p * 3] + t0; t1 = points[p * 3 + 1] + t1; t2 = points[p * 3 + 2] + t2; }
@@ -223,7 +250,11 @@ __global__ __launch_bounds__(LB) void add_dis_bwd_kernel(const float *__restrict
 
 // PoseNet-loss weights: wgt[n] = c_n (the 1/N and upstream factor go into wscale); d_c[n] = g (dis_n - w/c_n) / N
 __global__ __launch_bounds__(LB) void loss_dc_kernel(const float *__restrict__ pred_c, const float *__restrict__ dis, int N,
-                                                     float w, float g, float *__restrict__ d_c) {
+                                                     float w, float g, float *__restrict__ d_c, const FrameTab ft) {
+  {
+    const size_t fn = (size_t)ft.idx[blockIdx.y] * ft.N;
+    pred_c += fn; dis += fn; d_c += fn;
+  }
   for (int n = blockIdx.x * LB + threadIdx.x; n < N; n += gridDim.x * LB) d_c[n] = g * (dis[n] - w / pred_c[n]) / (float)N;
 }
 
@@ -234,11 +265,16 @@ __global__ __launch_bounds__(LB) void loss_finish_kernel(const float *__restrict
                                                          const float *__restrict__ target, const float *__restrict__ dis,
                                                          int N, int M, float w, float *__restrict__ loss_out,
                                                          float *__restrict__ dis_out, float *__restrict__ new_points,
-                                                         float *__restrict__ new_target) {
+                                                         float *__restrict__ new_target, const FrameTab ft) {
   __shared__ float s_red[LB];
   __shared__ float s_v[LB];
   __shared__ int s_i[LB];
   const int tid = threadIdx.x;
+  {
+    const size_t f = ft.idx[blockIdx.y], fn = f * ft.N;
+    pred_r += fn * 4; pred_t += fn * 3; pred_c += fn; points += fn * 3; target += f * ft.M * 3; dis += fn;
+    loss_out += f; dis_out += f; new_points += fn * 3; new_target += f * ft.M * 3;
+  }
   float acc = 0.f, best = -__builtin_inff();
   int bi = 0x7fffffff;
   for (int n = tid; n < N; n += LB) {
@@ -277,7 +313,11 @@ __global__ __launch_bounds__(LB) void loss_finish_kernel(const float *__restrict
 __global__ __launch_bounds__(LB) void recentre_kernel(const float *__restrict__ pred_r, const float *__restrict__ pred_t,
                                                       const float *__restrict__ points, const float *__restrict__ target,
                                                       int N, int M, float *__restrict__ new_points,
-                                                      float *__restrict__ new_target) {
+                                                      float *__restrict__ new_target, const FrameTab ft) {
+  {      // one pose per frame: pred_r [B][4], pred_t [B][3]
+    const size_t f = ft.idx[blockIdx.y];
+    pred_r += f * 4; pred_t += f * 3; points += f * N * 3; target += f * M * 3; new_points += f * N * 3; new_target += f * M * 3;
+  }
   const Rot R = quat_rot(pred_r);
   const float t0 = pred_t[0], t1 = pred_t[1], t2 = pred_t[2];
   for (int i = blockIdx.x * LB + threadIdx.x; i < N + M; i += gridDim.x * LB) {
@@ -425,6 +465,108 @@ void loss_lds_attrs() {
 
 using namespace df;
 
+namespace df {
+
+int launch_loss_frames(int B, const int *symmetric, const float *pred_r, const float *pred_t, const float *pred_c, const float *target,
+                       const float *model_points, const float *points, int N, int M, float w, float *loss_out, float *dis_out, float *new_points,
+                       float *new_target, float *dis_scratch, int *sel, hipStream_t st) {
+  if (B <= 0 || N <= 0) return set_error(DF_ERR_ARG, "loss_forward: B and N must be >= 1");
+  int rc = check_m(M, "loss_forward");
+  if (rc != DF_OK) return rc;
+  const size_t lds = (size_t)M * 16;
+  loss_lds_attrs();
+  const int ppb = M >= LB * SYM_QPL ? 1 : std::min(LB, (LB * SYM_QPL) / M);      // (the per-pose totals are kept by tid < ppb <= LB)
+  const size_t lds2 = (size_t)LB * SYM_QPL * 4 + (size_t)ppb * 4;
+  const bool fused = N >= 2 && lds2 <= 150 * 1024;
+  for (int b0 = 0; b0 < B; b0 += LOSS_MAX_FRAMES) {
+    FrameTab all{}, sym{}, non{};
+    all.N = sym.N = non.N = N; all.M = sym.M = non.M = M;
+    for (int b = b0; b < std::min(B, b0 + LOSS_MAX_FRAMES); ++b) {
+      all.idx[all.n++] = b;
+      if (symmetric && symmetric[b]) sym.idx[sym.n++] = b; else non.idx[non.n++] = b;
+    }
+    if (sym.n && fused)
+      // the fused transform + shared 1-NN scan (knn_core.h) + distance reduction; ppb whole poses per workgroup fill its 256 lanes x 2 queries
+      hipLaunchKernelGGL(add_dis_sym_kernel, dim3((N + ppb - 1) / ppb, sym.n), dim3(LB), lds2, st, pred_r, pred_t, points, target, model_points, N, M, ppb,
+                         dis_scratch, sel, sym);
+    else if (sym.n)
+      hipLaunchKernelGGL(add_dis_kernel, dim3(N, sym.n), dim3(LB), lds, st, pred_r, pred_t, points, target, model_points, M, 1, dis_scratch, sel, sym);
+    if (non.n)
+      hipLaunchKernelGGL(add_dis_kernel, dim3(N, non.n), dim3(LB), lds, st, pred_r, pred_t, points, target, model_points, M, 0, dis_scratch, (int *)nullptr, non);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1, all.n), dim3(LB), 0, st, pred_r, pred_t, pred_c, points, target, dis_scratch, N, M, w, loss_out, dis_out,
+                       new_points, new_target, all);
+  }
+  return check_launch("loss_forward");
+}
+
+int launch_loss_bwd_frames(int B, const int *symmetric, const float *pred_r, const float *pred_t, const float *pred_c, const float *target,
+                           const float *model_points, const float *points, const int *sel, const float *dis, int N, int M, float w, float g_loss,
+                           float *d_pred_r, float *d_pred_t, float *d_pred_c, hipStream_t st) {
+  if (B <= 0 || N <= 0 || M <= 0) return set_error(DF_ERR_ARG, "loss_backward: bad sizes");
+  for (int b0 = 0; b0 < B; b0 += LOSS_MAX_FRAMES) {
+    FrameTab all{}, sym{}, non{};
+    all.N = sym.N = non.N = N; all.M = sym.M = non.M = M;
+    for (int b = b0; b < std::min(B, b0 + LOSS_MAX_FRAMES); ++b) {
+      all.idx[all.n++] = b;
+      if (symmetric && symmetric[b]) sym.idx[sym.n++] = b; else non.idx[non.n++] = b;
+    }
+    if (sym.n)      // the nearest-neighbour matches of the forward pass enter as constants
+      hipLaunchKernelGGL(add_dis_bwd_kernel, dim3(N, sym.n), dim3(LB), 0, st, pred_r, pred_t, points, target, model_points, sel, M, pred_c, g_loss / (float)N,
+                         d_pred_r, d_pred_t, sym);
+    if (non.n)
+      hipLaunchKernelGGL(add_dis_bwd_kernel, dim3(N, non.n), dim3(LB), 0, st, pred_r, pred_t, points, target, model_points, (const int *)nullptr, M, pred_c,
+                         g_loss / (float)N, d_pred_r, d_pred_t, non);
+    hipLaunchKernelGGL(loss_dc_kernel, dim3(cdiv(N, LB), all.n), dim3(LB), 0, st, pred_c, dis, N, w, g_loss, d_pred_c, all);
+  }
+  return check_launch("loss_backward");
+}
+
+// Loss_refine (lib/loss_refiner.py:12-62) for B stacked frames, one pose each: pred_r [B][4], pred_t [B][3], points [B][N][3], target /
+// model_points [B][M][3] -> dis_out [B], new_points, new_target; sel [B][M] (written for symmetric frames)
+int launch_loss_refine_frames(int B, const int *symmetric, const float *pred_r, const float *pred_t, const float *target, const float *model_points,
+                              const float *points, int N, int M, float *dis_out, float *new_points, float *new_target, int *sel, hipStream_t st) {
+  if (B <= 0 || N <= 0) return set_error(DF_ERR_ARG, "loss_refine_forward: B and N must be >= 1");
+  int rc = check_m(M, "loss_refine_forward");
+  if (rc != DF_OK) return rc;
+  loss_lds_attrs();
+  for (int b0 = 0; b0 < B; b0 += LOSS_MAX_FRAMES) {
+    FrameTab all{}, sym{}, non{};
+    all.N = sym.N = non.N = 1; all.M = sym.M = non.M = M;          // one pose per frame: the per-frame strides of add_dis_kernel with N = 1
+    for (int b = b0; b < std::min(B, b0 + LOSS_MAX_FRAMES); ++b) {
+      all.idx[all.n++] = b;
+      if (symmetric && symmetric[b]) sym.idx[sym.n++] = b; else non.idx[non.n++] = b;
+    }
+    if (sym.n)
+      hipLaunchKernelGGL(add_dis_kernel, dim3(1, sym.n), dim3(LB), (size_t)M * 16, st, pred_r, pred_t, (const float *)nullptr, target, model_points, M, 1, dis_out,
+                         sel, sym);
+    if (non.n)
+      hipLaunchKernelGGL(add_dis_kernel, dim3(1, non.n), dim3(LB), (size_t)M * 16, st, pred_r, pred_t, (const float *)nullptr, target, model_points, M, 0, dis_out,
+                         (int *)nullptr, non);
+    hipLaunchKernelGGL(recentre_kernel, dim3(cdiv(N + M, LB), all.n), dim3(LB), 0, st, pred_r, pred_t, points, target, N, M, new_points, new_target, all);
+  }
+  return check_launch("loss_refine_forward");
+}
+
+int launch_loss_refine_bwd_frames(int B, const int *symmetric, const float *pred_r, const float *pred_t, const float *target, const float *model_points,
+                                  const int *sel, int M, float g_dis, float *d_pred_r, float *d_pred_t, hipStream_t st) {
+  if (B <= 0 || M <= 0) return set_error(DF_ERR_ARG, "loss_refine_backward: bad sizes");
+  for (int b0 = 0; b0 < B; b0 += LOSS_MAX_FRAMES) {
+    FrameTab sym{}, non{};
+    sym.N = non.N = 1; sym.M = non.M = M;
+    for (int b = b0; b < std::min(B, b0 + LOSS_MAX_FRAMES); ++b)
+      if (symmetric && symmetric[b]) sym.idx[sym.n++] = b; else non.idx[non.n++] = b;
+    if (sym.n)
+      hipLaunchKernelGGL(add_dis_bwd_kernel, dim3(1, sym.n), dim3(LB), 0, st, pred_r, pred_t, (const float *)nullptr, target, model_points, sel, M,
+                         (const float *)nullptr, g_dis, d_pred_r, d_pred_t, sym);
+    if (non.n)
+      hipLaunchKernelGGL(add_dis_bwd_kernel, dim3(1, non.n), dim3(LB), 0, st, pred_r, pred_t, (const float *)nullptr, target, model_points, (const int *)nullptr, M,
+                         (const float *)nullptr, g_dis, d_pred_r, d_pred_t, non);
+  }
+  return check_launch("loss_refine_backward");
+}
+
+}  // namespace df
+
 extern "C" int df_loss_forward(const float *pred_r, const float *pred_t, const float *pred_c, const float *target,
                                const float *model_points, const float *points, int N, int M, float w, int symmetric,
                                float *loss_out, float *dis_out, float *new_points, float *new_target, float *dis_scratch,
@@ -433,24 +575,45 @@ extern "C" int df_loss_forward(const float *pred_r, const float *pred_t, const f
       !new_target || !dis_scratch)
     return set_error(DF_ERR_ARG, "loss_forward: null pointer");
   if (N <= 0) return set_error(DF_ERR_ARG, "loss_forward: N must be >= 1");
-  int rc = check_m(M, "loss_forward");
-  if (rc != DF_OK) return rc;
-  hipStream_t st = to_stream(stream);
-  const size_t lds = (size_t)M * 16;
-  loss_lds_attrs();
-  const int ppb = M >= LB * SYM_QPL ? 1 : std::min(LB, (LB * SYM_QPL) / M);      // (the per-pose totals are kept by tid < ppb <= LB)
-  const size_t lds2 = (size_t)LB * SYM_QPL * 4 + (size_t)ppb * 4;
-  if (symmetric && N >= 2 && lds2 <= 150 * 1024) {
-    // the fused transform + shared 1-NN scan (knn_core.h) + distance reduction; ppb whole poses per workgroup fill its
-    // 256 lanes x 4 queries
-    hipLaunchKernelGGL(add_dis_sym_kernel, dim3((N + ppb - 1) / ppb), dim3(LB), lds2, st, pred_r, pred_t, points, target, model_points, N, M, ppb,
-                       dis_scratch, sel_out);
-  } else {
-    hipLaunchKernelGGL(add_dis_kernel, dim3(N), dim3(LB), lds, st, pred_r, pred_t, points, target, model_points, M, symmetric, dis_scratch, sel_out);
+  const int sym = symmetric != 0;
+  if (sym && !sel_out) {      // (the caller does not keep the matches: the one-frame kernels take a null selection buffer)
+    int rc = check_m(M, "loss_forward");
+    if (rc != DF_OK) return rc;
+    hipStream_t st = to_stream(stream);
+    loss_lds_attrs();
+    const int ppb = M >= LB * SYM_QPL ? 1 : std::min(LB, (LB * SYM_QPL) / M);
+    const size_t lds2 = (size_t)LB * SYM_QPL * 4 + (size_t)ppb * 4;
+    const FrameTab one = one_frame(N, M);
+    if (N >= 2 && lds2 <= 150 * 1024)
+      hipLaunchKernelGGL(add_dis_sym_kernel, dim3((N + ppb - 1) / ppb), dim3(LB), lds2, st, pred_r, pred_t, points, target, model_points, N, M, ppb,
+                         dis_scratch, (int *)nullptr, one);
+    else
+      hipLaunchKernelGGL(add_dis_kernel, dim3(N), dim3(LB), (size_t)M * 16, st, pred_r, pred_t, points, target, model_points, M, 1, dis_scratch, (int *)nullptr, one);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(LB), 0, st, pred_r, pred_t, pred_c, points, target, dis_scratch, N, M, w, loss_out, dis_out,
+                       new_points, new_target, one);
+    return check_launch("loss_forward");
   }
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(LB), 0, st, pred_r, pred_t, pred_c, points, target, dis_scratch, N, M, w,
-                     loss_out, dis_out, new_points, new_target);
-  return check_launch("loss_forward");
+  return launch_loss_frames(1, &sym, pred_r, pred_t, pred_c, target, model_points, points, N, M, w, loss_out, dis_out, new_points, new_target, dis_scratch,
+                            sel_out, to_stream(stream));
+}
+
+extern "C" int df_loss_forward_frames(int B, const int *symmetric, const float *pred_r, const float *pred_t, const float *pred_c, const float *target,
+                                      const float *model_points, const float *points, int N, int M, float w, float *loss_out, float *dis_out,
+                                      float *new_points, float *new_target, float *dis_scratch, int *sel_out, df_stream_t stream) {
+  if (!pred_r || !pred_t || !pred_c || !target || !model_points || !points || !loss_out || !dis_out || !new_points || !new_target || !dis_scratch)
+    return set_error(DF_ERR_ARG, "loss_forward_frames: null pointer");
+  if (B <= 0 || N <= 0) return set_error(DF_ERR_ARG, "loss_forward_frames: B and N must be >= 1");
+  if (!sel_out && symmetric) {      // no room for the matches: the symmetric frames go one at a time through the form that keeps none
+    for (int b = 0; b < B; ++b) {
+      const int rc = df_loss_forward(pred_r + (size_t)b * N * 4, pred_t + (size_t)b * N * 3, pred_c + (size_t)b * N, target + (size_t)b * M * 3,
+                                     model_points + (size_t)b * M * 3, points + (size_t)b * N * 3, N, M, w, symmetric[b], loss_out + b, dis_out + b,
+                                     new_points + (size_t)b * N * 3, new_target + (size_t)b * M * 3, dis_scratch + (size_t)b * N, nullptr, stream);
+      if (rc != DF_OK) return rc;
+    }
+    return DF_OK;
+  }
+  return launch_loss_frames(B, symmetric, pred_r, pred_t, pred_c, target, model_points, points, N, M, w, loss_out, dis_out, new_points, new_target, dis_scratch,
+                            sel_out, to_stream(stream));
 }
 
 extern "C" int df_loss_refine_forward(const float *pred_r, const float *pred_t, const float *target, const float *model_points,
@@ -464,8 +627,8 @@ extern "C" int df_loss_refine_forward(const float *pred_r, const float *pred_t, 
   hipStream_t st = to_stream(stream);
   loss_lds_attrs();
   hipLaunchKernelGGL(add_dis_kernel, dim3(1), dim3(LB), (size_t)M * 16, st, pred_r, pred_t, (const float *)nullptr, target,
-                     model_points, M, symmetric, dis_out, sel_out);
-  hipLaunchKernelGGL(recentre_kernel, dim3(cdiv(N + M, LB)), dim3(LB), 0, st, pred_r, pred_t, points, target, N, M, new_points, new_target);
+                     model_points, M, symmetric, dis_out, sel_out, one_frame(1, M));
+  hipLaunchKernelGGL(recentre_kernel, dim3(cdiv(N + M, LB)), dim3(LB), 0, st, pred_r, pred_t, points, target, N, M, new_points, new_target, one_frame(1, M));
   return check_launch("loss_refine_forward");
 }
 
@@ -494,12 +657,9 @@ extern "C" int df_loss_backward(const float *pred_r, const float *pred_t, const 
                                 float w, float g_loss, float *d_pred_r, float *d_pred_t, float *d_pred_c, df_stream_t stream) {
   if (!pred_r || !pred_t || !pred_c || !target || !model_points || !points || !dis || !d_pred_r || !d_pred_t || !d_pred_c)
     return set_error(DF_ERR_ARG, "loss_backward: null pointer");
-  if (N <= 0 || M <= 0) return set_error(DF_ERR_ARG, "loss_backward: bad sizes");
-  hipStream_t st = to_stream(stream);
-  hipLaunchKernelGGL(add_dis_bwd_kernel, dim3(N), dim3(LB), 0, st, pred_r, pred_t, points, target, model_points, sel, M, pred_c,
-                     g_loss / (float)N, d_pred_r, d_pred_t);
-  hipLaunchKernelGGL(loss_dc_kernel, dim3(cdiv(N, LB)), dim3(LB), 0, st, pred_c, dis, N, w, g_loss, d_pred_c);
-  return check_launch("loss_backward");
+  const int sym = sel != nullptr;
+  return launch_loss_bwd_frames(1, &sym, pred_r, pred_t, pred_c, target, model_points, points, sel, dis, N, M, w, g_loss, d_pred_r, d_pred_t, d_pred_c,
+                                to_stream(stream));
 }
 
 extern "C" int df_loss_refine_backward(const float *pred_r, const float *pred_t, const float *target, const float *model_points,
@@ -507,7 +667,7 @@ extern "C" int df_loss_refine_backward(const float *pred_r, const float *pred_t,
   if (!pred_r || !pred_t || !target || !model_points || !d_pred_r || !d_pred_t) return set_error(DF_ERR_ARG, "loss_refine_backward: null pointer");
   if (M <= 0) return set_error(DF_ERR_ARG, "loss_refine_backward: bad sizes");
   hipLaunchKernelGGL(add_dis_bwd_kernel, dim3(1), dim3(LB), 0, to_stream(stream), pred_r, pred_t, (const float *)nullptr, target,
-                     model_points, sel, M, (const float *)nullptr, g_dis, d_pred_r, d_pred_t);
+                     model_points, sel, M, (const float *)nullptr, g_dis, d_pred_r, d_pred_t, one_frame(1, M));
   return check_launch("loss_refine_backward");
 }
 

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "igemm.h"
+#include "loss.h"
 #include "layers.h"
 #include "wino.h"
 
@@ -2000,15 +2001,11 @@ void posenet_step(Step &s, const PoseNetIO &io) {
   float *dis_n = s.f((size_t)B * N);
   int *sel = reinterpret_cast<int *>(s.bytes((size_t)B * N * io.M * sizeof(int)));
   float *np = io.new_points ? io.new_points : s.f((size_t)B * N * 3), *nt = io.new_target ? io.new_target : s.f((size_t)B * io.M * 3);
-  for (int b = 0; b < B && s.live(); ++b) {
-    const int sym = io.symmetric ? io.symmetric[b] : 0;
-    int *sb = sel + (size_t)b * N * io.M;
-    s.fail(df_loss_forward(out_r + (size_t)b * N * 4, out_t + (size_t)b * N * 3, out_c + (size_t)b * N, io.target + (size_t)b * io.M * 3,
-                           io.model_points + (size_t)b * io.M * 3, io.cloud + (size_t)b * N * 3, N, io.M, io.w, sym, io.loss + b, io.dis + b,
-                           np + (size_t)b * N * 3, nt + (size_t)b * io.M * 3, dis_n + (size_t)b * N, sym ? sb : nullptr, s.st));
-    s.fail(df_loss_backward(out_r + (size_t)b * N * 4, out_t + (size_t)b * N * 3, out_c + (size_t)b * N, io.target + (size_t)b * io.M * 3,
-                            io.model_points + (size_t)b * io.M * 3, io.cloud + (size_t)b * N * 3, sym ? sb : nullptr, dis_n + (size_t)b * N, N, io.M,
-                            io.w, 1.f, d_r + (size_t)b * N * 4, d_t + (size_t)b * N * 3, d_c + (size_t)b * N, s.st));
+  if (s.live()) {      // all frames of the pass in a handful of launches (csrc/loss.h), frame by frame the arithmetic of df_loss_forward / _backward
+    s.fail(launch_loss_frames(B, io.symmetric, out_r, out_t, out_c, io.target, io.model_points, io.cloud, N, io.M, io.w, io.loss, io.dis, np, nt, dis_n, sel,
+                              s.st));
+    s.fail(launch_loss_bwd_frames(B, io.symmetric, out_r, out_t, out_c, io.target, io.model_points, io.cloud, sel, dis_n, N, io.M, io.w, 1.f, d_r, d_t, d_c,
+                                  s.st));
   }
   s.dbg("forward + loss");
   // ---- backward: the last head layer by hand, then the tape in reverse ----
@@ -2127,14 +2124,10 @@ void refiner_step(Step &s, const RefinerIO &io) {
     hipLaunchKernelGGL(refiner_tail_fwd_kernel, dim3(B), dim3(64), 0, s.st, f2->v.d, s.p("conv3_r.weight"), s.p("conv3_r.bias"), s.p("conv3_t.weight"),
                        s.p("conv3_t.bias"), io.obj, t.K, out_r, out_t, B);
   int *sel = reinterpret_cast<int *>(s.bytes((size_t)B * io.M * sizeof(int)));
-  for (int b = 0; b < B && s.live(); ++b) {
-    const int sym = io.symmetric ? io.symmetric[b] : 0;
-    int *sb = sel + (size_t)b * io.M;
-    s.fail(df_loss_refine_forward(out_r + b * 4, out_t + b * 3, io.target + (size_t)b * io.M * 3, io.model_points + (size_t)b * io.M * 3,
-                                  io.points + (size_t)b * N * 3, N, io.M, sym, io.dis + b, io.new_points + (size_t)b * N * 3,
-                                  io.new_target + (size_t)b * io.M * 3, sym ? sb : nullptr, s.st));
-    s.fail(df_loss_refine_backward(out_r + b * 4, out_t + b * 3, io.target + (size_t)b * io.M * 3, io.model_points + (size_t)b * io.M * 3,
-                                   sym ? sb : nullptr, io.M, 1.f, d_r + b * 4, d_t + b * 3, s.st));
+  if (s.live()) {      // all frames in a handful of launches (csrc/loss.h)
+    s.fail(launch_loss_refine_frames(B, io.symmetric, out_r, out_t, io.target, io.model_points, io.points, N, io.M, io.dis, io.new_points, io.new_target, sel,
+                                     s.st));
+    s.fail(launch_loss_refine_bwd_frames(B, io.symmetric, out_r, out_t, io.target, io.model_points, sel, io.M, 1.f, d_r, d_t, s.st));
   }
   {
     s.grad_of(f2);

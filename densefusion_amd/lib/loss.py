@@ -76,3 +76,28 @@ class Loss:
         return _LossFn.apply(pred_r, pred_t, pred_c, target, model_points, points, w, sym, M)
 
     __call__ = forward
+
+    def forward_frames(self, pred_r, pred_t, pred_c, target, model_points, idx, points, w, refine):
+        """``forward`` for B stacked frames in a handful of launches (``df_loss_forward_frames``), WITHOUT an autograd graph: pred_r [B,N,4],
+        pred_t [B,N,3], pred_c [B,N,1]|[B,N], target / model_points [B,M,3], points [B,N,3]; ``idx``: host object indices (an int per
+        frame) -> (loss [B], dis [B], new_points [B,N,3], new_target [B,M,3]).  Each frame's numbers are those of a ``forward`` call on it.
+        (The refiner phase of tools/train.py asks for the whole window's re-centred points at once.)"""
+        import ctypes
+        pr, pt, pc, tg, mp, pts = (_f32(t) for t in (pred_r, pred_t, pred_c, target, model_points, points))
+        B, N, M, dev = pr.shape[0], pr.shape[1], self.num_pt_mesh, pr.device
+        if pr.shape != (B, N, 4) or pt.shape != (B, N, 3) or pc.numel() != B * N or tg.shape != (B, M, 3) or mp.shape != (B, M, 3) or pts.shape != (B, N, 3):
+            raise RuntimeError("Loss.forward_frames: expected pred_r [B,N,4], pred_t [B,N,3], pred_c [B,N], target / model_points [B,M,3], points [B,N,3]")
+        sym = [int((not refine) and int(i) in self.sym_list) for i in idx]
+        if len(sym) != B:
+            raise RuntimeError("Loss.forward_frames: one object index per frame")
+        loss, dis = torch.empty(B, device=dev), torch.empty(B, device=dev)
+        new_points, new_target = torch.empty(B, N, 3, device=dev), torch.empty(B, M, 3, device=dev)
+        scratch = torch.empty(B, N, device=dev)
+        sel = torch.empty(B, N, M, dtype=torch.int32, device=dev) if any(sym) else None
+        with _lib.device_guard(dev):
+            st = _lib.lib().df_loss_forward_frames(B, (ctypes.c_int * B)(*sym), pr.data_ptr(), pt.data_ptr(), pc.data_ptr(), tg.data_ptr(), mp.data_ptr(),
+                                                   pts.data_ptr(), N, M, float(w), loss.data_ptr(), dis.data_ptr(), new_points.data_ptr(),
+                                                   new_target.data_ptr(), scratch.data_ptr(), sel.data_ptr() if sel is not None else None,
+                                                   _lib.current_stream())
+        _lib.check(st, "loss_forward_frames")
+        return loss, dis, new_points, new_target

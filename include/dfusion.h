@@ -149,6 +149,15 @@ int df_loss_forward(const float *pred_r, const float *pred_t, const float *pred_
                     float *loss_out, float *dis_out, float *new_points, float *new_target, float *dis_scratch,
                     int *sel_out /* optional [N][M]: matched target index per transformed point, for backward */,
                     df_stream_t stream);
+/* df_loss_forward for B stacked frames in a handful of launches (each frame's arithmetic is df_loss_forward's): pred_r [B][N][4],
+ * pred_t [B][N][3], pred_c [B][N], target / model_points [B][M][3], points [B][N][3]; symmetric: HOST int [B] (or NULL = none)
+ * -> loss_out [B], dis_out [B], new_points [B][N][3], new_target [B][M][3]; dis_scratch: B*N floats; sel_out: optional [B][N][M]
+ * (needed when any frame is symmetric and the matches are wanted; NULL: the symmetric frames do not keep them).  What the trainer's
+ * window passes call (tools/train.py:139-153 runs lib/loss.py once per frame). */
+int df_loss_forward_frames(int B, const int *symmetric, const float *pred_r, const float *pred_t, const float *pred_c,
+                           const float *target, const float *model_points, const float *points, int N, int M, float w,
+                           float *loss_out, float *dis_out, float *new_points, float *new_target, float *dis_scratch,
+                           int *sel_out, df_stream_t stream);
 int df_loss_refine_forward(const float *pred_r, const float *pred_t, const float *target, const float *model_points,
                            const float *points, int N, int M, int symmetric, float *dis_out, float *new_points,
                            float *new_target, int *sel_out /* optional [M] */, df_stream_t stream);

@@ -175,3 +175,27 @@ def test_symmetric_loss_matches_are_df_knn_bit_for_bit():
     gathered = tgt[sel_l.reshape(-1)].view(N, M, 3)
     dis_ref = torch.norm(pred.permute(1, 2, 0) - gathered, dim=2).mean(1)
     _close(scratch, dis_ref, 2e-6)
+
+
+@pytest.mark.parametrize("refine", [False, True])
+def test_stacked_frames_give_each_frames_own_numbers(refine):
+    """df_loss_forward_frames (Loss.forward_frames): B stacked frames, symmetric and not, in a handful of launches == B Loss.forward calls, bit for
+    bit (the trainer's passes and the refiner phase's re-centring call it instead of looping over the frames)."""
+    from densefusion_amd.lib.loss import Loss
+    B, N, M = 5, 200, 120
+    rng = np.random.Generator(np.random.PCG64(77))
+    objs = [synth.make_object(9100 + b, 80, 80, N, 13, num_points_mesh=M) for b in range(B)]
+    C = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    q, pt = C(rng.standard_normal((B, N, 4)).astype(np.float32)), C((rng.standard_normal((B, N, 3)) * 0.03).astype(np.float32))
+    pc = C(rng.uniform(0.05, 0.95, (B, N, 1)).astype(np.float32))
+    tgt, mp, pts = (C(np.stack([o[k] for o in objs])) for k in ("target", "model_points", "cloud"))
+    ids = [7, 3, 8, 7, 1]                                           # 7 and 8 are symmetric
+    crit = Loss(M, [7, 8])
+    loss, dis, npts, ntg = crit.forward_frames(q, pt, pc, tgt, mp, ids, pts, 0.015, refine)
+    assert loss.shape == (B,) and dis.shape == (B,) and npts.shape == (B, N, 3) and ntg.shape == (B, M, 3)
+    for b in range(B):
+        one = crit(q[b:b + 1], pt[b:b + 1], pc[b:b + 1], tgt[b:b + 1], mp[b:b + 1], torch.tensor([[ids[b]]]), pts[b:b + 1], 0.015, refine)
+        assert torch.equal(one[0].reshape(()), loss[b]) and torch.equal(one[1].reshape(()), dis[b])
+        assert torch.equal(one[2][0], npts[b]) and torch.equal(one[3][0], ntg[b])
+    with pytest.raises(RuntimeError):
+        crit.forward_frames(q, pt, pc, tgt, mp, ids[:3], pts, 0.015, refine)

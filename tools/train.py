@@ -340,9 +340,9 @@ def main(argv=None):
                 part = [f for group in by_size.values() for f in group]
                 cat = lambda k: torch.cat([f[k] for f in part])
                 pred_r, pred_t, pred_c, e = estimator.forward_multi([torch.cat([f[2] for f in group]) for group in by_size.values()], cat(0), cat(1), cat(5))
-                for b, f in enumerate(part):
-                    _, _, npt, ntg = criterion(pred_r[b:b + 1], pred_t[b:b + 1], pred_c[b:b + 1], f[3], f[4], f[5], f[0], opt.w, True)
-                    new_points.append(npt); new_target.append(ntg)
+                _, _, npt, ntg = criterion.forward_frames(pred_r, pred_t, pred_c, cat(3), cat(4), [train_utils.host_index(f[5]) for f in part], cat(0),
+                                                          opt.w, True)           # lib/loss.py per frame, all frames of the chunk in one call
+                new_points.append(npt); new_target.append(ntg)
                 order += part; emb.append(e)
             new_points, new_target, emb = torch.cat(new_points), torch.cat(new_target), torch.cat(emb)
         idx, model_points = torch.cat([f[5] for f in order]), torch.cat([f[4] for f in order])
