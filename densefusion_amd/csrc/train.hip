@@ -1009,6 +1009,41 @@ __global__ __launch_bounds__(TB) void flip_all_kernel(const float *__restrict__ 
   }
 }
 
+// The same copies as 32 x 32 (output channel, input channel) tiles through LDS: reads run along c (the source's fastest axis), writes along n
+// (the destination's) -- the element-wise form read with a stride of T * I floats (167 us per optimizer step for PoseNet's 86 MB; this one is
+// bound by the copy).  Tile list: `tbegin` = first tile of the segment in the launch's tile space; a tile = (z, tap, n block, c block).
+struct FlipTile { long off; int tbegin; int O, T, I, KH, KW, Z, nb_n, nb_c; };
+__global__ __launch_bounds__(256) void flip_tiles_kernel(const float *__restrict__ P, float *__restrict__ wf, const FlipTile *__restrict__ segs, int nseg) {
+  __shared__ float s_t[32][33];
+  int lo = 0, hi = nseg - 1;
+  while (lo < hi) {                               // last segment whose tbegin <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (segs[mid].tbegin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const FlipTile sg = segs[lo];
+  int q = (int)blockIdx.x - sg.tbegin;
+  const int cb = q % sg.nb_c; q /= sg.nb_c;
+  const int nb = q % sg.nb_n; q /= sg.nb_n;
+  const int t = q % sg.T, z = q / sg.T;
+  const int ky = t / sg.KW, kx = t - ky * sg.KW;
+  const int tf = (sg.KH - 1 - ky) * sg.KW + (sg.KW - 1 - kx);
+  const long per = (long)sg.O * sg.T * sg.I;
+  const float *src = P + sg.off + z * per;
+  float *dst = wf + sg.off + z * per;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = nb * 32 + ty + r * 8, c = cb * 32 + tx;
+    s_t[ty + r * 8][tx] = n < sg.O && c < sg.I ? src[((size_t)n * sg.T + tf) * sg.I + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = cb * 32 + ty + r * 8, n = nb * 32 + tx;
+    if (n < sg.O && c < sg.I) dst[((size_t)c * sg.T + t) * sg.O + n] = s_t[tx][ty + r * 8];
+  }
+}
+
 // layout conversion between the reference's state-dict tensors and the flat kernel layout
 //   mode 0: OIHW [O][I][T] <-> O(T)Ipad          mode 1: OIHW (T = 9) <-> tap-major [9][O][I]          (dir 0: pack, 1: unpack)
 __global__ __launch_bounds__(TB) void relayout_kernel(const float *__restrict__ src, float *__restrict__ dst, int O, int I, int T, int Ipad, int mode,
@@ -1066,6 +1101,8 @@ struct Trainer {
   size_t wino_floats = 0;
   FlipSeg *flip_tab = nullptr;     // device copy of `flips` for the one-launch flip
   long flip_total = 0;
+  FlipTile *flip_tiles = nullptr;  // the tiled form's segment table
+  int flip_ntiles = 0;
   bool splitk = true;             // df_trainer_set_splitk
   // df_trainer_profile: HIP event pairs around every MFMA launch of a step, executed FLOPs per kind (0 fwd, 1 dgrad, 2 wgrad)
   bool profiling = false;
@@ -1619,7 +1656,9 @@ int check_flips(Trainer &t, const float *P, long version, hipStream_t st) {
   if (!t.wflip || (t.wino_floats && !t.wino_buf))
     return set_error(DF_ERR_STATE, "trainer: created without a device (no arena for the data gradients' weight copies)");
   if (t.flip_version == version && t.flip_src == P && version >= 0) return DF_OK;
-  if (t.flip_tab)
+  if (t.flip_tiles)
+    hipLaunchKernelGGL(flip_tiles_kernel, dim3(t.flip_ntiles), dim3(256), 0, st, P, t.wflip, t.flip_tiles, (int)t.flips.size());
+  else if (t.flip_tab)
     hipLaunchKernelGGL(flip_all_kernel, dim3(nblk(t.flip_total, 8192)), dim3(TB), 0, st, P, t.wflip, t.flip_tab, (int)t.flips.size(), t.flip_total);
   else
     for (const Trainer::Flip &f : t.flips)
@@ -2176,6 +2215,17 @@ extern "C" df_trainer *df_trainer_create(int kind, int num_points, int num_obj) 
     if (t->wflip && hipMalloc(&t->flip_tab, tab.size() * sizeof(FlipSeg)) == hipSuccess)
       hipMemcpy(t->flip_tab, tab.data(), tab.size() * sizeof(FlipSeg), hipMemcpyHostToDevice);
     else { (void)hipGetLastError(); t->flip_tab = nullptr; }
+    std::vector<FlipTile> tiles;
+    long tb = 0;
+    for (const Trainer::Flip &f : t->flips) {
+      const int nb_n = (f.O + 31) / 32, nb_c = (f.I + 31) / 32;
+      tiles.push_back(FlipTile{(long)f.off, (int)tb, f.O, f.T, f.I, f.KH, f.KW, f.Z, nb_n, nb_c});
+      tb += (long)f.Z * f.T * nb_n * nb_c;
+    }
+    t->flip_ntiles = (int)tb;
+    if (t->wflip && !tiles.empty() && tb < (1L << 31) && hipMalloc(&t->flip_tiles, tiles.size() * sizeof(FlipTile)) == hipSuccess)
+      hipMemcpy(t->flip_tiles, tiles.data(), tiles.size() * sizeof(FlipTile), hipMemcpyHostToDevice);
+    else { (void)hipGetLastError(); t->flip_tiles = nullptr; }
   }
   return reinterpret_cast<df_trainer *>(t);
 }
@@ -2186,6 +2236,7 @@ extern "C" void df_trainer_destroy(df_trainer *h) {
   if (t->wflip) hipFree(t->wflip);
   if (t->wino_buf) hipFree(t->wino_buf);
   if (t->flip_tab) hipFree(t->flip_tab);
+  if (t->flip_tiles) hipFree(t->flip_tiles);
   for (auto e : t->ev) hipEventDestroy(e);
   delete t;
 }
