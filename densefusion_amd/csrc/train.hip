@@ -767,9 +767,12 @@ __global__ __launch_bounds__(64) void cloud_conv1_bwd_kernel(const float *__rest
 __global__ __launch_bounds__(64) void cloud_conv1_bwd_finish_kernel(const float *__restrict__ part, int count, float *__restrict__ dw, float *__restrict__ db) {
   const int c = threadIdx.x;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int i = 0; i < count; ++i)
+#pragma unroll 8
+  for (int i = 0; i < count; ++i) {        // (eight loads in flight; the additions stay in order)
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(part + ((size_t)i * 64 + c) * 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) a[e] += part[((size_t)i * 64 + c) * 4 + e];
+    for (int e = 0; e < 4; ++e) a[e] += v[e];
+  }
   dw[c * 3 + 0] += a[0]; dw[c * 3 + 1] += a[1]; dw[c * 3 + 2] += a[2];
   db[c] += a[3];
 }
@@ -911,18 +914,31 @@ __global__ __launch_bounds__(TB) void head_final_wgrad_finish_kernel(const float
   const int i = blockIdx.x * TB + threadIdx.x;
   if (i >= 8 * 128) return;
   const int j = i >> 7, k = i & 127;
-  for (int b = 0; b < B; ++b) {
-    long ob = obj[b];
-    ob = ob < 0 ? 0 : (ob >= num_obj ? num_obj - 1 : ob);
-    float a = 0.f;
-    for (int ch = 0; ch < chunks; ++ch) a += part[(((size_t)b * chunks + ch) * 8 + j) * 128 + k];
-    float *dst = j < 4 ? dw_r + (ob * 4 + j) * 128 : j < 7 ? dw_t + (ob * 3 + (j - 4)) * 128 : dw_c + ob * 128;
-    dst[k] += a;
-    if (k == 0) {
-      float s = 0.f;
-      for (int ch = 0; ch < chunks; ++ch) s += zpart[((size_t)b * chunks + ch) * 8 + j];
-      float *bd = j < 4 ? db_r + ob * 4 + j : j < 7 ? db_t + ob * 3 + (j - 4) : db_c + ob;
-      *bd += s;
+  for (int b0 = 0; b0 < B; b0 += 4) {          // four frames' partial sums are gathered first (their loads in flight together), then added in frame order
+    float a4[4] = {0.f, 0.f, 0.f, 0.f}, s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = b0 + u;
+      if (b >= B) break;
+#pragma unroll 8
+      for (int ch = 0; ch < chunks; ++ch) a4[u] += part[(((size_t)b * chunks + ch) * 8 + j) * 128 + k];
+      if (k == 0) {
+#pragma unroll 8
+        for (int ch = 0; ch < chunks; ++ch) s4[u] += zpart[((size_t)b * chunks + ch) * 8 + j];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = b0 + u;
+      if (b >= B) break;
+      long ob = obj[b];
+      ob = ob < 0 ? 0 : (ob >= num_obj ? num_obj - 1 : ob);
+      float *dst = j < 4 ? dw_r + (ob * 4 + j) * 128 : j < 7 ? dw_t + (ob * 3 + (j - 4)) * 128 : dw_c + ob * 128;
+      dst[k] += a4[u];
+      if (k == 0) {
+        float *bd = j < 4 ? db_r + ob * 4 + j : j < 7 ? db_t + ob * 3 + (j - 4) : db_c + ob;
+        *bd += s4[u];
+      }
     }
   }
 }
