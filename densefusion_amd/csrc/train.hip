@@ -578,10 +578,13 @@ __global__ __launch_bounds__(TB) void upconv_gather_bwd_multi_kernel(const float
 // aux0 = the buckets' first rows at the pooled level
 __global__ __launch_bounds__(TB) void maxpool3s2_bwd_multi_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx, int C,
                                                                   const BTab tab) {
+  // thread = 4 channels of one input pixel (16-byte loads; the per-channel decisions and the order of the additions are those of the
+  // one-channel form: 79 -> 25 us on the stem's 8 x 80 x 80 x 64 map)
+  const int C4 = C / 4;
   const long r_lo = tab.row0[0], nrow = tab.row1[tab.n - 1] - r_lo;
-  GRID_STRIDE(i, nrow * C) {
-    const int c = (int)(i % C);
-    const long row = r_lo + i / C;
+  GRID_STRIDE(i, nrow * C4) {
+    const int c = (int)(i % C4) * 4;
+    const long row = r_lo + i / C4;
     const int g = tab_of_row(tab, row);
     const int H = tab.H[g], W = tab.W[g], OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
     long l = row - tab.row0[g];
@@ -590,28 +593,34 @@ __global__ __launch_bounds__(TB) void maxpool3s2_bwd_multi_kernel(const float *_
     const int b = (int)(l / H);
     const float *xb = x + (tab.row0[g] + (long)b * H * W) * C + c;
     const float *dyb = dy + (tab.aux0[g] + (long)b * OH * OW) * C + c;
-    const float xv = xb[((long)iy * W + ix) * C];
-    float acc = 0.f;
+    const f32x4 xv = *reinterpret_cast<const f32x4 *>(xb + ((long)iy * W + ix) * C);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int oy = (iy + 1) / 2 - 1 < 0 ? 0 : (iy + 1) / 2 - 1; oy <= (iy + 1) / 2 && oy < OH; ++oy) {
       if (iy < oy * 2 - 1 || iy > oy * 2 + 1) continue;
       for (int ox = (ix + 1) / 2 - 1 < 0 ? 0 : (ix + 1) / 2 - 1; ox <= (ix + 1) / 2 && ox < OW; ++ox) {
         if (ix < ox * 2 - 1 || ix > ox * 2 + 1) continue;
-        bool win = true;
-        for (int ky = 0; ky < 3 && win; ++ky) {
+        bool win[4] = {true, true, true, true};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
           const int yy = oy * 2 - 1 + ky;
           if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
             const int xx = ox * 2 - 1 + kx;
             if ((unsigned)xx >= (unsigned)W) continue;
-            const float v = xb[((long)yy * W + xx) * C];
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + ((long)yy * W + xx) * C);
             const bool earlier = yy < iy || (yy == iy && xx < ix);
-            if (v > xv || (earlier && v == xv)) { win = false; break; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (v[e] > xv[e] || (earlier && v[e] == xv[e])) win[e] = false;
           }
         }
-        if (win) acc += dyb[((long)oy * OW + ox) * C];
+        const f32x4 d = *reinterpret_cast<const f32x4 *>(dyb + ((long)oy * OW + ox) * C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += win[e] ? d[e] : 0.f;
       }
     }
-    dx[row * C + c] = acc;
+    *reinterpret_cast<f32x4 *>(dx + row * C + c) = acc;
   }
 }
 
@@ -1823,7 +1832,7 @@ void posenet_step(Step &s, const PoseNetIO &io) {
       s.grad_of(stem);
       if (s.live())
         for (const BTab &t : make_tabs(ls, lx))
-          hipLaunchKernelGGL(maxpool3s2_bwd_multi_kernel, dim3(nblk(tab_rows(t) * 64)), dim3(TB), 0, s.st, stem->v.d, xp->g.d, stem->g.d, 64, t);
+          hipLaunchKernelGGL(maxpool3s2_bwd_multi_kernel, dim3(nblk(tab_rows(t) * 16)), dim3(TB), 0, s.st, stem->v.d, xp->g.d, stem->g.d, 64, t);
     });
   }
   int cin = 64;
