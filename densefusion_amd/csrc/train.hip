@@ -549,6 +549,21 @@ __global__ __launch_bounds__(TB) void upconv_gather_bwd_multi_kernel(const float
     bil_cands(qy, h, OH, 1, ylo, yhi);
     bil_cands(qx, w, OW, 1, xlo, xhi);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // the column candidates' weights once per thread (they were recomputed under every row candidate); same products, same order
+    constexpr int MAXC = 8;      // (a source column feeds at most 5 upsampled columns at scale 2)
+    float wxs[MAXC];
+    int pxs[MAXC];
+    int ncx = 0;
+    for (int ux = xlo; ux <= xhi && ncx < MAXC; ++ux) {
+      const int px = ux - dx + 1;
+      if ((unsigned)px >= (unsigned)OW) continue;
+      int x0, x1;
+      float wx0, wx1;
+      bil_src(ux, w, OW, 1, x0, x1, wx0, wx1);
+      if (x0 != qx && x1 != qx) continue;
+      wxs[ncx] = (x0 == qx ? wx0 : 0.f) + (x1 == qx ? wx1 : 0.f);
+      pxs[ncx++] = px;
+    }
     for (int uy = ylo; uy <= yhi; ++uy) {
       const int py = uy - dy + 1;
       if ((unsigned)py >= (unsigned)OH) continue;
@@ -557,17 +572,10 @@ __global__ __launch_bounds__(TB) void upconv_gather_bwd_multi_kernel(const float
       bil_src(uy, h, OH, 1, y0, y1, wy0, wy1);
       if (y0 != qy && y1 != qy) continue;
       const float wy = (y0 == qy ? wy0 : 0.f) + (y1 == qy ? wy1 : 0.f);
-      for (int ux = xlo; ux <= xhi; ++ux) {
-        const int px = ux - dx + 1;
-        if ((unsigned)px >= (unsigned)OW) continue;
-        int x0, x1;
-        float wx0, wx1;
-        bil_src(ux, w, OW, 1, x0, x1, wx0, wx1);
-        if (x0 != qx && x1 != qx) continue;
-        const float wx = (x0 == qx ? wx0 : 0.f) + (x1 == qx ? wx1 : 0.f);
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(g + ((long)(b * OH + py) * OW + px) * Cout + c);
+      for (int k = 0; k < ncx; ++k) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(g + ((long)(b * OH + py) * OW + pxs[k]) * Cout + c);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += (wy * wx) * v[e];
+        for (int e = 0; e < 4; ++e) acc[e] += (wy * wxs[k]) * v[e];
       }
     }
     reinterpret_cast<f32x4 *>(dY)[(row * 9 + tap) * C4 + c / 4] = acc;
@@ -811,8 +819,12 @@ __global__ __launch_bounds__(256) void colsum_obj_kernel(const float *__restrict
   const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + col, b = blockIdx.y;
   float a = 0.f;
-  if (c < C)
-    for (int r = rl; r < Npad && (long)b * Npad + r < rows_total; r += 8) a += g[((size_t)b * Npad + r) * g_ld + c];
+  if (c < C) {
+    const long left = rows_total - (long)b * Npad;
+    const int rmax = (int)(left < Npad ? left : Npad);
+#pragma unroll 8
+    for (int r = rl; r < rmax; r += 8) a += g[((size_t)b * Npad + r) * g_ld + c];      // (loads ahead, the additions in row order)
+  }
   s_p[rl][col] = a;
   __syncthreads();
   if (rl == 0 && c < C) {
