@@ -199,3 +199,21 @@ def test_stacked_frames_give_each_frames_own_numbers(refine):
         assert torch.equal(one[2][0], npts[b]) and torch.equal(one[3][0], ntg[b])
     with pytest.raises(RuntimeError):
         crit.forward_frames(q, pt, pc, tgt, mp, ids[:3], pts, 0.015, refine)
+
+
+def test_more_stacked_frames_than_one_launch_table_holds():
+    """65 frames: the frame table of a launch holds 60, the rest goes to a second round of launches -- same numbers frame by frame."""
+    from densefusion_amd.lib.loss import Loss
+    B, N, M = 65, 48, 40
+    rng = np.random.Generator(np.random.PCG64(78))
+    C = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    q, pt = C(rng.standard_normal((B, N, 4)).astype(np.float32)), C((rng.standard_normal((B, N, 3)) * 0.03).astype(np.float32))
+    pc = C(rng.uniform(0.05, 0.95, (B, N, 1)).astype(np.float32))
+    tgt, mp = C(rng.standard_normal((B, M, 3)).astype(np.float32) * 0.1), C(rng.standard_normal((B, M, 3)).astype(np.float32) * 0.1)
+    pts = C(rng.standard_normal((B, N, 3)).astype(np.float32) * 0.1)
+    ids = [7 if b % 3 == 0 else 2 for b in range(B)]
+    crit = Loss(M, [7])
+    loss, dis, npts, ntg = crit.forward_frames(q, pt, pc, tgt, mp, ids, pts, 0.015, False)
+    for b in (0, 1, 59, 60, 63, 64):
+        one = crit(q[b:b + 1], pt[b:b + 1], pc[b:b + 1], tgt[b:b + 1], mp[b:b + 1], torch.tensor([[ids[b]]]), pts[b:b + 1], 0.015, False)
+        assert torch.equal(one[0].reshape(()), loss[b]) and torch.equal(one[1].reshape(()), dis[b]) and torch.equal(one[2][0], npts[b]), b
