@@ -453,3 +453,47 @@ def test_trainer_profile_reports_executed_flops_per_kind():
         assert ms > 0 and fl > 0 and n > 10, (kind, ms, fl, n)
     # the weight gradients contract exactly the forward launches' shapes except the Winograd-domain ones (fewer multiplies forward)
     assert prof["wgrad"][1] >= prof["fwd"][1] * 0.9
+
+
+def test_crops_that_are_not_multiples_of_8_through_the_training_step():
+    """The datasets snap crops to multiples of 40, the entry points accept any H, W >= 8: a 44 x 52 frame against the oracle's autograd (forward
+    outputs, loss and every parameter gradient), and a window of 44 x 52 / 92 x 108 / 40 x 80 frames as one multi-bucket pass against its one-frame
+    passes (split-K off: one summation order per output element)."""
+    K, N, M = 2, 64, 60
+    sd = synth.make_state_dict(synth.posenet_spec(K), 29)
+    o = synth.make_object(1201, 44, 52, N, K, num_points_mesh=M)
+    o["obj"][0] = 1
+    idx = torch.tensor([[1]])
+    T = lambda k: torch.from_numpy(o[k])[None]
+    psd = {k: torch.from_numpy(v).clone().requires_grad_() for k, v in sd.items()}
+    r, t, c, emb = dfnet.posenet_forward(psd, T("img"), T("cloud"), torch.from_numpy(o["choose"]), idx)
+    want_loss, want_dis, _, _ = loss_ref.loss_calculation(r, t, c, T("target"), T("model_points"), idx, T("cloud"), 0.015, False, M, [1])
+    want_loss.backward()
+    tr = _trainer("posenet", N, K, sd)
+    f = _frames([o])
+    out = tr.step_posenet(f["img"], f["cloud"], f["choose"], f["obj"], f["target"], f["model_points"], [True], 0.015, dropout=False, want_pred=True)
+    _close(out["pred_r"], r, 2e-4, "pred_r"); _close(out["emb"], emb, 2e-4, "emb"); _close(out["loss"], want_loss.reshape(1), 1e-4, "loss")
+    for key, g in tr.grad_dict().items():
+        if "classifier" not in key:
+            _close(g, psd[key].grad, 2e-3, key)
+    sizes = [(44, 52), (92, 108), (40, 80), (44, 52)]
+    objs = [synth.make_object(1300 + i, h, w, N, K, num_points_mesh=M) for i, (h, w) in enumerate(sizes)]
+    frames = [dict(img=torch.from_numpy(q["img"]).to(DEV), cloud=torch.from_numpy(q["cloud"]).to(DEV), choose=torch.from_numpy(q["choose"]).to(DEV),
+                   obj=torch.from_numpy(q["obj"]).to(DEV), target=torch.from_numpy(q["target"]).to(DEV), model_points=torch.from_numpy(q["model_points"]).to(DEV),
+                   symmetric=int(q["obj"][0]) == 1) for q in objs]
+    tr.set_splitk(False)
+    tr.zero_grad()
+    outw, order = tr.step_posenet_window(frames, 0.015, dropout=False)
+    g_multi = tr.grad_dict()
+    tr.zero_grad()
+    for row, j in enumerate(order):
+        q = frames[j]
+        o1 = tr.step_posenet(q["img"][None], q["cloud"][None], q["choose"].reshape(1, -1), q["obj"].reshape(1), q["target"][None], q["model_points"][None],
+                             [q["symmetric"]], 0.015, dropout=False)
+        for k in ("loss", "dis", "emb"):
+            _close(outw[k][row:row + 1], o1[k], 2e-5, k)
+    for k, v in tr.grad_dict().items():
+        if "classifier" in k:
+            continue
+        scale = max(float(v.abs().max()), 1e-12)
+        assert float((g_multi[k] - v).abs().max()) / scale <= 5e-6, k
