@@ -353,8 +353,34 @@ def bench_loss():
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
-    return {"N": N, "M": M, "pairs": N * M * M, "us_per_forward": round(us, 2), "achieved_TFLOPs": round(9.0 * N * M * M / us / 1e6, 2),
-            "fp32_valu_frac": round(9.0 * N * M * M / us / 1e6 / FP32_PEAK_TFLOPS, 4)}
+    res = {"N": N, "M": M, "pairs": N * M * M, "us_per_forward": round(us, 2), "achieved_TFLOPs": round(9.0 * N * M * M / us / 1e6, 2),
+           "fp32_valu_frac": round(9.0 * N * M * M / us / 1e6 / FP32_PEAK_TFLOPS, 4)}
+    # what the training step runs since round 4: the symmetric frames of a pass stacked in ONE launch (df_loss_forward_frames; a pass of 8
+    # frames has 4 symmetric ones in the bench's mix) -- the same per-frame arithmetic on a 4x larger grid
+    F = 4
+    rep = lambda t: t[None].repeat(F, *([1] * t.dim())).contiguous()
+    qF, ptF, pcF, tgF, mpF, ptsF = rep(q), rep(pt), rep(pc), rep(tgt), rep(mp), rep(pts)
+    lossF, disF = torch.empty(F, device=dev), torch.empty(F, device=dev)
+    npF, ntF, scF = torch.empty(F, N, 3, device=dev), torch.empty(F, M, 3, device=dev), torch.empty(F, N, device=dev)
+    selF = torch.empty(F, N, M, dtype=torch.int32, device=dev)
+    symF = (ctypes.c_int * F)(*([1] * F))
+
+    def call_frames():
+        _lib.check(L.df_loss_forward_frames(F, symF, qF.data_ptr(), ptF.data_ptr(), pcF.data_ptr(), tgF.data_ptr(), mpF.data_ptr(), ptsF.data_ptr(), N, M,
+                                            ctypes.c_float(0.015), lossF.data_ptr(), disF.data_ptr(), npF.data_ptr(), ntF.data_ptr(), scF.data_ptr(),
+                                            selF.data_ptr(), _lib.current_stream()), "loss_forward_frames")
+    for _ in range(3):
+        call_frames()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        call_frames()
+    e1.record()
+    torch.cuda.synchronize()
+    usF = e0.elapsed_time(e1) / 20 / F * 1e3
+    res["stacked_4_frames"] = {"us_per_frame": round(usF, 2), "fp32_valu_frac": round(9.0 * N * M * M / usF / 1e6 / FP32_PEAK_TFLOPS, 4),
+                               "same_numbers_as_single_frame": bool(torch.equal(disF[0], dis[0]) and torch.equal(lossF[F - 1], loss[0]))}
+    return res
 
 
 def bench_entry_point(est, ref, device, windows=9, frames=56):
