@@ -1608,7 +1608,8 @@ WgradPlan wgrad_plan(const ConvParams &p, int nseg, const WgradSeg *segs) {
   w.tiles = ((p.Cout + tn - 1) / tn) * ((K + tk - 1) / tk);
   // split the pixel range so that one round of workgroups (WGRAD_OCC per CU) is in flight, each with at least 256 pixels
   long split = (256 * WGRAD_OCC) / w.tiles;
-  const long max_split = (M + 255) / 256;
+  const long min_px = w.tiles <= 16 ? 128 : 256;        // few output tiles (the per-point layers: 1 - 10): finer slices keep more CUs busy
+  const long max_split = (M + min_px - 1) / min_px;
   if (split > max_split) split = max_split;
   if (split > 256) split = 256;          // (the partial slices are re-read by the reduction)
   if (split < 1) split = 1;

@@ -1138,6 +1138,9 @@ struct Trainer {
   size_t wino_floats = 0;
   FlipSeg *flip_tab = nullptr;     // device copy of `flips` for the one-launch flip
   long flip_total = 0;
+#ifdef DF_DEV
+  std::vector<std::string> ev_desc;      // shape of every profiled launch (DF_PROFILE_VERBOSE)
+#endif
   FlipTile *flip_tiles = nullptr;  // the tiled form's segment table
   int flip_ntiles = 0;
   bool splitk = true;             // df_trainer_set_splitk
@@ -1378,18 +1381,23 @@ struct Step {
     }
     hipEventRecord(t->ev[t->ev_used], st);
   }
-  void prof_end(int kind, double flops) {
+  void prof_end(int kind, double flops, const ConvParams *p = nullptr, long M = 0) {
     if (!t->profiling || !live()) return;
     hipEventRecord(t->ev[t->ev_used + 1], st);
     t->ev_kind.push_back(kind);
     t->ev_flops.push_back(flops);
+#ifdef DF_DEV
+    char d[160] = "";
+    if (p) snprintf(d, sizeof(d), "M=%ld N=%d K=%d k%dx%d s%d d%d z%d", M > 0 ? M : (long)p->B * p->OH * p->OW, p->Cout, p->KH * p->KW * p->Cin, p->KH, p->KW, p->stride, p->dil, p->zcount);
+    t->ev_desc.push_back(d);
+#endif
     t->ev_used += 2;
   }
   void gemm(int kind, const ConvParams &p) {
     if (!live()) return;
     prof_begin();
     fail(launch_conv(p, st));
-    prof_end(kind, conv_flops(p));
+    prof_end(kind, conv_flops(p), &p);
   }
   // the same convolution over several buckets: one launch (launch_conv_multi)
   void gemm_multi(int kind, const ConvParams &p, const std::vector<WgradSeg> &segs) {
@@ -1398,7 +1406,9 @@ struct Step {
     for (const WgradSeg &g : segs) fl += 2.0 * g.B * g.OH * g.OW * (double)p.Cout * p.KH * p.KW * p.Cin;
     prof_begin();
     fail(launch_conv_multi(p, (int)segs.size(), segs.data(), st));
-    prof_end(kind, fl);
+    long M = 0;
+    for (const WgradSeg &g : segs) M += (long)g.B * g.OH * g.OW;
+    prof_end(kind, fl, &p, M);
   }
   size_t slot(const std::string &name) {
     auto it = t->slot.find(name);
@@ -1494,7 +1504,7 @@ void wgrad(Step &s, ConvParams f, const std::vector<WgradSeg> &segs, View gy, fl
     for (const WgradSeg &g : segs) M += (double)g.B * g.OH * g.OW;
     s.prof_begin();
     s.fail(launch_wgrad_multi(f, (int)segs.size(), segs.data(), dw, db, ws, need, s.st, 1));
-    s.prof_end(GK_WGRAD, 2.0 * M * f.Cout * f.KH * f.KW * f.Cin);
+    s.prof_end(GK_WGRAD, 2.0 * M * f.Cout * f.KH * f.KW * f.Cin, &f, (long)M);
   }
   s.dbg("wgrad");
   s.off = mark;
@@ -2427,7 +2437,16 @@ extern "C" int df_trainer_profile_read(df_trainer *h, double *ms3, double *flops
     if (hipEventElapsedTime(&ms, t->ev[i], t->ev[i + 1]) != hipSuccess) return set_error(DF_ERR_LAUNCH, "trainer_profile_read: events not complete");
     const int k = t->ev_kind[i / 2];
     ms3[k] += ms; flops3[k] += t->ev_flops[i / 2]; launches3[k] += 1;
+#ifdef DF_DEV
+    static const bool verbose = dev_getenv("DF_PROFILE_VERBOSE") != nullptr;      // dev switch: one line per MFMA launch of the profiled steps
+    if (verbose && i / 2 < t->ev_desc.size())
+      fprintf(stderr, "[df-train-gemm] %s %-44s %9.1f us %7.1f TFLOP/s\n", k == 0 ? "fwd  " : k == 1 ? "dgrad" : "wgrad", t->ev_desc[i / 2].c_str(), ms * 1e3,
+              t->ev_flops[i / 2] / (ms * 1e-3) / 1e12);
+#endif
   }
+#ifdef DF_DEV
+  t->ev_desc.clear();
+#endif
   t->ev_used = 0;
   t->ev_kind.clear();
   t->ev_flops.clear();
