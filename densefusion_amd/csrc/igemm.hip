@@ -1097,6 +1097,40 @@ struct WgTab {
 // workgroup the main loop keeps the matrix pipe 95 % busy (tools/dev/wgrad_trace.hip); what is left is the prologue's first loads, the
 // 64 KB partial tile every workgroup stores and the reduce launch behind it.
 constexpr int WGRAD_OCC = 3;
+// The bias gradient (column sums of dY): stage 1 = bias_grad_kernel, stage 2 as extra workgroups of the slice reduction's launch (or
+// bias_reduce_kernel when there is no slice reduction).
+struct BiasJob { const float *dy; float *part; int M, C, ld, coff, rows, ncx, nblk; };
+// part[by][c] = sum over row block `by` of dY[m][c]: 4 row-interleaved partial sums per channel, added in a fixed order
+__device__ __forceinline__ void bias_grad_body(const BiasJob &j, int cx, int by) {
+  __shared__ float s_b[4][64];
+  const int c = cx * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int r0 = by * j.rows, r1 = min(j.M, r0 + j.rows);
+  float a = 0.f;
+  if (c < j.C) {
+#pragma unroll 8
+    for (int r = r0 + part; r < r1; r += 4) a += j.dy[(size_t)r * j.ld + j.coff + c];      // (loads ahead, the additions in row order)
+  }
+  s_b[part][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (part == 0 && c < j.C) j.part[(size_t)by * j.C + c] = (s_b[0][threadIdx.x] + s_b[1][threadIdx.x]) + (s_b[2][threadIdx.x] + s_b[3][threadIdx.x]);
+}
+// db[c] = sum_b part[b][c]: 8 lanes per channel add b = l, l + 8, ... in ascending order, then meet in LDS in lane order
+__device__ __forceinline__ void bias_reduce_body(const float *__restrict__ part, float *__restrict__ db, int C, int nblk, int accumulate, int bx) {
+  __shared__ float s_r[8][32];
+  const int col = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const int c = bx * 32 + col;
+  float a = 0.f;
+  if (c < C)
+    for (int b = zl; b < nblk; b += 8) a += part[(size_t)b * C + c];
+  s_r[zl][col] = a;
+  __syncthreads();
+  if (zl == 0 && c < C) {
+#pragma unroll
+    for (int l = 1; l < 8; ++l) a += s_r[l][col];
+    db[c] = accumulate ? db[c] + a : a;
+  }
+}
+
 template <int TN_, int OCC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void wgrad_f32_v2_kernel(const ConvParams p, float *__restrict__ part, int steps_per_chunk, int split,
                                                                                                           unsigned in_bytes, unsigned out_bytes, const WgTab tab) {
@@ -1265,10 +1299,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 // dw[i] = sum_z part[z][i], bit-reproducible: 8 z-lanes per output vector each add their slices z = l, l + 8, ... in ascending
 // order (8 independent load chains instead of one of length `split`), then the 8 partial sums meet in LDS and are added in
 // lane order.  32 float4 outputs per workgroup.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, long n4, int split, int accumulate) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, long n4, int split, int accumulate, int red_blocks,
+                                                           const float *__restrict__ bpart, float *__restrict__ db, int bC, int bnblk) {
+  if ((int)blockIdx.x >= red_blocks) {      // the bias gradient's second stage rides along (workgroups past the slice reduction's)
+    bias_reduce_body(bpart, db, bC, bnblk, accumulate, (int)blockIdx.x - red_blocks);
+    return;
+  }
   __shared__ f32x4 s_p[8][32];
   const int col = threadIdx.x & 31, zl = threadIdx.x >> 5;
-  for (long i0 = blockIdx.x * 32L; i0 < n4; i0 += (long)gridDim.x * 32) {
+  for (long i0 = blockIdx.x * 32L; i0 < n4; i0 += (long)red_blocks * 32) {
     const long i = i0 + col;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (i < n4)
@@ -1295,37 +1334,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
   }
 }
 
-// part[blockIdx.y][c] = sum over the block's rows of dY[m][c]  (summed over the row blocks by bias_reduce_kernel)
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float *__restrict__ dy, int M, int C, int ld, int coff,
-                                                        float *__restrict__ db, int rows_per_block) {
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
-  __shared__ float s[4][64];
-  float a = 0.f;
-  if (c < C) {
-#pragma unroll 8
-    for (int r = r0 + part; r < r1; r += 4) a += dy[(size_t)r * ld + coff + c];      // (loads ahead, the additions in row order)
-  }
-  s[part][threadIdx.x & 63] = a;
-  __syncthreads();
-  if (part == 0 && c < C) db[(size_t)blockIdx.y * C + c] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
-}
-
-// db[c] = sum_b part[b][c]: 8 lanes per channel add b = l, l + 8, ... in ascending order, then meet in LDS in lane order
+// the two stages as launches of their own (the small-shape product kernel; a gradient that needs no slice reduction)
+__global__ __launch_bounds__(256) void bias_grad_kernel(const BiasJob j) { bias_grad_body(j, blockIdx.x, blockIdx.y); }
 __global__ __launch_bounds__(256) void bias_reduce_kernel(const float *__restrict__ part, float *__restrict__ db, int C, int nblk, int accumulate) {
-  __shared__ float s_p[8][32];
-  const int col = threadIdx.x & 31, zl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + col;
-  float a = 0.f;
-  if (c < C)
-    for (int b = zl; b < nblk; b += 8) a += part[(size_t)b * C + c];
-  s_p[zl][col] = a;
-  __syncthreads();
-  if (zl == 0 && c < C) {
-#pragma unroll
-    for (int l = 1; l < 8; ++l) a += s_p[l][col];
-    db[c] = accumulate ? db[c] + a : a;
-  }
+  bias_reduce_body(part, db, C, nblk, accumulate, blockIdx.x);
 }
 
 
@@ -1665,6 +1677,14 @@ static int launch_wgrad_segs(ConvParams p, int nseg, const WgradSeg *segs, float
   const bool reduce = w.split > 1 || accumulate;
   float *part = reduce ? static_cast<float *>(ws) : dw;
   float *bpart = static_cast<float *>(ws) + w.part_floats;
+  // the bias gradient (dY's rows of all buckets are contiguous: one column sum over them): stage 1 is a launch of its own (as extra workgroups of
+  // the product kernel it ran at that kernel's 3 workgroups per CU with 34 KB of LDS each: a latency-bound loop at low occupancy, 32-frame
+  // window 1 679 -> 1 402 frames/s), stage 2 rides along in the slice reduction's launch
+  BiasJob bj{};
+  if (db) {
+    bj.dy = p.out + out_lo * p.out_ld; bj.part = bpart; bj.M = (int)M; bj.C = p.Cout; bj.ld = p.out_ld; bj.coff = p.out_coff;
+    bj.rows = w.bias_rows; bj.ncx = (p.Cout + 63) / 64; bj.nblk = w.nblk;
+  }
   if (w.big) {
     WgTab tab;
     tab.n = nseg;
@@ -1711,13 +1731,13 @@ static int launch_wgrad_segs(ConvParams p, int nseg, const WgradSeg *segs, float
       z += zc;
     }
   }
+  if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(bj.ncx, bj.nblk), dim3(256), 0, st, bj);
   if (reduce) {
     const long n4 = (long)p.Cout * K / 4;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((n4 + 31) / 32, 8192)), dim3(256), 0, st, part, dw, n4, w.split, accumulate);
-  }
-  if (db) {     // dY's rows of all buckets are contiguous: one column sum over them
-    const float *dy = p.out + out_lo * p.out_ld;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3((p.Cout + 63) / 64, w.nblk), dim3(256), 0, st, dy, (int)M, p.Cout, p.out_ld, p.out_coff, bpart, w.bias_rows);
+    const int red_blocks = (int)std::min<long>((n4 + 31) / 32, 8192), extra = db ? (p.Cout + 31) / 32 : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(red_blocks + extra)), dim3(256), 0, st, part, dw, n4, w.split, accumulate, red_blocks, bpart, db, p.Cout,
+                       w.nblk);
+  } else if (db) {
     hipLaunchKernelGGL(bias_reduce_kernel, dim3((p.Cout + 31) / 32), dim3(256), 0, st, bpart, db, p.Cout, w.nblk, accumulate);
   }
   return check_launch("wgrad");
