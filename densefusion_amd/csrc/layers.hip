@@ -514,7 +514,8 @@ __global__ __launch_bounds__(TPB) void colsum_finish_kernel(const float *__restr
   for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
     const long b = i / C, c = i - b * C;
     float s = 0.f;
-    for (int r = 0; r < rows_per_obj; ++r) s += partial[((size_t)b * rows_per_obj + r) * C + c];
+#pragma unroll 8
+    for (int r = 0; r < rows_per_obj; ++r) s += partial[((size_t)b * rows_per_obj + r) * C + c];      // (loads ahead, the additions in row order)
     mean[i] = s / (float)N;
   }
 }
