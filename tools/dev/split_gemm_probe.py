@@ -15,6 +15,8 @@ dev = torch.device("cuda")
 SHAPES = [("psp bottleneck (1/8 res), K=1024->2304 stacked", 139000, 2304, 1024), ("per-point 512->1024", 286720, 1024, 512),
           ("up_1 1x1 part 1024->512 @ 1/8", 139000, 1024, 512), ("per-point 640->256", 286720, 256, 640), ("per-point 256->512", 286720, 512, 256),
           ("small-M tail", 1000, 512, 512), ("M not a multiple of 128", 12345, 256, 192)]
+if len(sys.argv) > 1:
+    SHAPES = [SHAPES[int(a)] for a in sys.argv[1:]]
 out = {"mode": mode, "shapes": []}
 keep = []          # the weight planes are cached per (pointer, size): no weight buffer may be recycled inside this process
 for name, M, N, K in SHAPES:
