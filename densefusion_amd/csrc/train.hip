@@ -1140,6 +1140,8 @@ struct Trainer {
   long flip_total = 0;
 #ifdef DF_DEV
   std::vector<std::string> ev_desc;      // shape of every profiled launch (DF_PROFILE_VERBOSE)
+  hipStream_t side = nullptr;            // DF_TRAIN_OVERLAP experiment
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 #endif
   FlipTile *flip_tiles = nullptr;  // the tiled form's segment table
   int flip_ntiles = 0;
@@ -1344,6 +1346,13 @@ struct Step {
   std::deque<Act> acts;
   std::deque<Lv> lvs;
   std::vector<std::function<void()>> tape;
+#ifdef DF_DEV
+  // development experiment (DF_TRAIN_OVERLAP=1): a layer's weight gradient on a side stream beside its data gradient; joined before the layer's
+  // backward closure ends, so no buffer hazard crosses a layer (profiles/r04_experiments/README.md)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool keep_wgrad_ws = false;
+#endif
 
   void *bytes(size_t b) {
     b = (b + 255) & ~size_t(255);
@@ -1499,15 +1508,32 @@ void wgrad(Step &s, ConvParams f, const std::vector<WgradSeg> &segs, View gy, fl
   const size_t mark = s.off;
   const size_t need = wgrad_multi_workspace_bytes(f, (int)segs.size(), segs.data());
   void *ws = s.bytes(need);
+  hipStream_t st = s.st;
+  bool keep = false;
+#ifdef DF_DEV
+  keep = s.keep_wgrad_ws;
+  if (keep && s.live() && s.side) {      // fork: the side stream starts where the main stream is now
+    hipEventRecord(s.ev_fork, s.st);
+    hipStreamWaitEvent(s.side, s.ev_fork, 0);
+    st = s.side;
+  }
+#endif
   if (s.live()) {
     double M = 0;
     for (const WgradSeg &g : segs) M += (double)g.B * g.OH * g.OW;
     s.prof_begin();
-    s.fail(launch_wgrad_multi(f, (int)segs.size(), segs.data(), dw, db, ws, need, s.st, 1));
+    s.fail(launch_wgrad_multi(f, (int)segs.size(), segs.data(), dw, db, ws, need, st, 1));
     s.prof_end(GK_WGRAD, 2.0 * M * f.Cout * f.KH * f.KW * f.Cin, &f, (long)M);
   }
+#ifdef DF_DEV
+  if (keep && s.live() && s.side) {
+    hipEventRecord(s.ev_join, s.side);
+    static const bool sync_dbg = df::dev_getenv("DF_TRAIN_OVERLAP_SYNC") != nullptr;      // A/B: the side stream drained at once (no concurrency left)
+    if (sync_dbg) hipStreamSynchronize(s.side);
+  }
+#endif
   s.dbg("wgrad");
-  s.off = mark;
+  if (!keep) s.off = mark;          // (overlap experiment: the partial slices stay allocated until the layer's closure joins the side stream)
 }
 // a launch that is one bucket by itself (plain GEMMs over rows; `f` carries B / H / W / OH / OW)
 void wgrad(Step &s, const ConvParams &f, View gy, float *dw, float *db) {
@@ -1625,6 +1651,13 @@ Act *conv(Step &s, Act *x, int cin, const ConvW &cw, int cout, int k, int stride
     Step &s = *sp;
     s.dbg("conv bwd begin", cw.name);
     if (act != ACT_NONE) launch_act_bwd(s, y, act, slope, act == ACT_PRELU ? s.gr(cw.slope) : nullptr);
+#ifdef DF_DEV
+    static const bool overlap = df::dev_getenv("DF_TRAIN_OVERLAP") != nullptr;
+    s.keep_wgrad_ws = overlap && need_dx;
+    bool acc_early = false;
+    if (s.keep_wgrad_ws) acc_early = s.grad_of(x);      // x's gradient buffer outlives the layer: it is taken BELOW the slices that are released at the join
+    const size_t mark_layer = s.off;
+#endif
     {   // weight gradient: one contraction over every bucket's pixels
       std::vector<WgradSeg> segs;
       if (flat) segs.push_back(WgradSeg{(int)x->rows(), 1, 1, 1, 1, 0, 0});
@@ -1634,7 +1667,11 @@ Act *conv(Step &s, Act *x, int cin, const ConvW &cw, int cout, int k, int stride
       wgrad(s, f, segs, y->g, s.gr(cw.name, cw.woff), cw.bias.empty() ? nullptr : s.gr(cw.bias, cw.boff));
     }
     if (need_dx) {
+#ifdef DF_DEV
+      const bool acc = s.keep_wgrad_ws ? acc_early : s.grad_of(x);
+#else
       const bool acc = s.grad_of(x);
+#endif
       if (flat) dgrad(s, (*plan)[0], y->g, x->g, s.pf(cw.name, cw.woff), acc);
       else {
         std::vector<int> direct;
@@ -1678,6 +1715,13 @@ Act *conv(Step &s, Act *x, int cin, const ConvW &cw, int cout, int k, int stride
         wino_pass(s, y->g, cout, s.dry || !wino_ok ? nullptr : s.t->wino_buf + wit->second.bwd, x->g, cin, acc ? x->g.d : nullptr, x->g.ld, ACT_NONE, GK_DGRAD);
       }
     }
+#ifdef DF_DEV
+    if (s.keep_wgrad_ws) {      // join: nothing after this layer may touch dY / the slices before its weight gradient is done
+      if (s.live() && s.side) hipStreamWaitEvent(s.st, s.ev_join, 0);
+      s.off = mark_layer;
+      s.keep_wgrad_ws = false;
+    }
+#endif
     if (res) {
       if (!res->gset) { res->g = y->g; res->gset = true; }          // the residual's gradient IS this (masked) gradient: alias, no copy
       else if (s.live()) hipLaunchKernelGGL(add2d_kernel, dim3(nblk(y->rows() * (y->C / 4))), dim3(TB), 0, s.st, res->g.d, res->g.ld, y->g.d, y->g.ld,
@@ -2387,6 +2431,16 @@ extern "C" int df_posenet_train_step_multi(df_trainer *h, const float *flat_para
   rc = check_flips(t, flat_param, (long)param_version, to_stream(stream));
   if (rc != DF_OK) return rc;
   Step s{&t, to_stream(stream), false, static_cast<char *>(ws)};
+#ifdef DF_DEV
+  if (df::dev_getenv("DF_TRAIN_OVERLAP")) {
+    if (!t.side) {
+      hipStreamCreateWithFlags(&t.side, hipStreamNonBlocking);
+      hipEventCreateWithFlags(&t.ev_fork, hipEventDisableTiming);
+      hipEventCreateWithFlags(&t.ev_join, hipEventDisableTiming);
+    }
+    s.side = t.side; s.ev_fork = t.ev_fork; s.ev_join = t.ev_join;
+  }
+#endif
   s.cap = ws_bytes; s.P = flat_param; s.G = flat_grad;
   PoseNetIO io{nb, B, H, W, img, M, cloud, target, model_points, choose, obj, symmetric_host, w, dropout, seed, loss_out, dis_out, new_points, new_target,
                out_r, out_t, out_c, emb};
